@@ -1,0 +1,222 @@
+/*
+ * lvgpu.h -- C ABI of liblvgpu.so: LVGL 8.x's software pixel path (fill / alpha blend / RGB565 conversion /
+ * flush rotate) as batched HIP kernels for AMD Instinct MI355X (gfx950).
+ *
+ * Everything here is plain C: pointers, sizes and PODs, no LVGL, HIP or torch types.  Buffers named "device" are
+ * HIP device pointers (hipMalloc, lvgpu_malloc, or a torch tensor's data_ptr()); `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  Every entry point returns LVGPU_OK (0) or a negative LVGPU_ERR_* code and
+ * never throws; lvgpu_last_error() gives the text of the last failure on the calling thread.  Calls are
+ * asynchronous with respect to the host unless stated otherwise.  Entry points may be called from several host
+ * threads as long as each thread uses its own device/stream.
+ *
+ * Pixel vocabulary (libraries/lvgl/src/misc/lv_color.h:208-222): a pixel is lv_color16_t, 2 bytes.
+ *   color_16_swap = 1 : LV_COLOR_16_SWAP 1, memory bytes {RRRRRGGG, GGGBBBBB} (big-endian RGB565 = panel wire order)
+ *   color_16_swap = 0 : LV_COLOR_16_SWAP 0, little-endian RGB565
+ * Areas are LVGL areas: int16 {x1,y1,x2,y2}, inclusive, absolute (libraries/lvgl/src/misc/lv_area.h:43-48).
+ *
+ * The LVGL-signature plug-in callbacks built on these live in lvgpu_lvgl.h.
+ */
+#ifndef LVGPU_H
+#define LVGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVGPU_VERSION 0x000100
+
+#define LVGPU_OK 0
+#define LVGPU_ERR_ARG (-1)         /* malformed descriptor (NULL buffer, negative count, bad enum, ...) */
+#define LVGPU_ERR_HIP (-2)         /* a HIP runtime call failed; see lvgpu_last_error() */
+#define LVGPU_ERR_UNSUPPORTED (-3) /* valid LVGL request this library does not implement */
+#define LVGPU_ERR_NO_DEVICE (-4)   /* no gfx950 device visible */
+
+/* lv_area_t (libraries/lvgl/src/misc/lv_area.h:43-48), same layout. */
+typedef struct {
+    int16_t x1, y1, x2, y2;
+} lvgpu_area_t;
+
+/* lv_draw_mask_res_t (libraries/lvgl/src/draw/lv_draw_mask.h:35-42). */
+enum { LVGPU_MASK_RES_TRANSP = 0, LVGPU_MASK_RES_FULL_COVER = 1, LVGPU_MASK_RES_CHANGED = 2, LVGPU_MASK_RES_UNKNOWN = 3 };
+
+/* lv_blend_mode_t (libraries/lvgl/src/misc/lv_style.h:86-94). */
+enum {
+    LVGPU_BLEND_NORMAL = 0,
+    LVGPU_BLEND_ADDITIVE = 1,
+    LVGPU_BLEND_SUBTRACTIVE = 2,
+    LVGPU_BLEND_MULTIPLY = 3,
+    LVGPU_BLEND_REPLACE = 4
+};
+
+/* lv_disp_rot_t as src/lv_port.c:466-546 interprets it (NOT lv_refr.c's own sw_rotate, which mirrors 90/270). */
+enum { LVGPU_ROT_NONE = 0, LVGPU_ROT_90 = 1, LVGPU_ROT_180 = 2, LVGPU_ROT_270 = 3 };
+
+/* What `src` of a blend holds. */
+enum {
+    LVGPU_SRC_FILL = 0,     /* no image: fill with `color` (lv_draw_sw_blend_dsc_t.src_buf == NULL)                  */
+    LVGPU_SRC_RGB565 = 1,   /* lv_color_t image, 2 B/px, same byte order as the destination                         */
+    LVGPU_SRC_ARGB8888 = 2, /* lv_color32_t image, bytes {B,G,R,A} (libraries/lvgl/src/misc/lv_color.h:224-232):  */
+                            /* colour truncated to 565 (lv_color_make, :148-154), A used as the per-pixel mask,     */
+                            /* i.e. lv_png.c:244-253 + lv_draw_sw_img.c:249-275 fused in front of map_normal        */
+    LVGPU_SRC_RGBA8888 = 3, /* same, bytes {R,G,B,A} as lodepng delivers them                                       */
+    LVGPU_SRC_ARGB8565 = 4  /* LV_IMG_CF_TRUE_COLOR_ALPHA at depth 16: 3 B/px {c.lo, c.hi, A}                      */
+                            /* (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:249-275)                                */
+};
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Library / device                                                                                             */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* Select and initialise a device (hipSetDevice + a first kernel load).  Returns LVGPU_ERR_NO_DEVICE when no HIP
+ * device exists.  Optional: every entry point works on the calling thread's current device. */
+int lvgpu_init(int device);
+int lvgpu_version(void);
+const char * lvgpu_last_error(void);
+int lvgpu_device_count(void);
+
+/* Device memory helpers so that a C host needs no HIP headers. */
+int lvgpu_malloc(void ** dev_ptr, size_t bytes);
+int lvgpu_free(void * dev_ptr);
+int lvgpu_memcpy_h2d(void * dev_dst, const void * host_src, size_t bytes, void * stream);
+int lvgpu_memcpy_d2h(void * host_dst, const void * dev_src, size_t bytes, void * stream);
+int lvgpu_memset(void * dev_dst, int value, size_t bytes, void * stream);
+int lvgpu_stream_synchronize(void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Blend: lv_draw_sw_blend over a batch of frames                                                               */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * One lv_draw_sw_blend call (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:95-204) applied to n_frames independent
+ * destination buffers.  Field-for-field it is lv_draw_ctx_t {buf, buf_area, clip_area}
+ * (libraries/lvgl/src/draw/lv_draw.h:59-73) plus lv_draw_sw_blend_dsc_t
+ * (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.h:29-39), with pointers replaced by device pointers + per-frame
+ * strides.  Strides follow the reference: destination row stride = width(buf_area) (:117), source row stride =
+ * width(blend_area) (:140), mask row stride = width(mask_area) (:158).
+ *
+ * Frame f uses dst + f*dst_frame_stride pixels, src + f*src_frame_stride pixels (0 = one image shared by all
+ * frames), mask + f*mask_frame_stride bytes (0 = shared).
+ *
+ * Semantics replaced: lv_draw_sw_blend gate (opa <= LV_OPA_MIN -> no-op; empty clip -> no-op, :95-106),
+ * lv_draw_sw_blend_basic mask_res handling (:111-115), fill_normal (:242-375), map_normal (:641-734), and with
+ * src_format ARGB8888/RGBA8888/ARGB8565 the colour/alpha split in front of them.  Results are bit-exact.
+ */
+typedef struct {
+    void * dst;               /* device: n_frames destination buffers of lv_color_t                              */
+    int64_t dst_frame_stride; /* pixels between consecutive frames' buffers                                      */
+    lvgpu_area_t buf_area;    /* draw_ctx->buf_area                                                              */
+    lvgpu_area_t clip_area;   /* draw_ctx->clip_area                                                             */
+    lvgpu_area_t blend_area;  /* dsc->blend_area                                                                 */
+    const void * src;         /* device, or NULL when src_format == LVGPU_SRC_FILL                               */
+    int64_t src_frame_stride; /* source pixels between frames, 0 = shared                                        */
+    const uint8_t * mask;     /* device A8 mask or NULL (dsc->mask_buf); must be NULL for the *8888/8565 formats */
+    int64_t mask_frame_stride; /* bytes between frames, 0 = shared                                               */
+    lvgpu_area_t mask_area;   /* dsc->mask_area (ignored when mask == NULL)                                      */
+    int32_t n_frames;
+    int32_t src_format;       /* LVGPU_SRC_*                                                                     */
+    uint16_t color;           /* dsc->color.full (fill colour)                                                   */
+    uint8_t mask_res;         /* dsc->mask_res                                                                   */
+    uint8_t opa;              /* dsc->opa                                                                        */
+    uint8_t blend_mode;       /* dsc->blend_mode (LVGPU_BLEND_*)                                                 */
+    uint8_t color_16_swap;    /* LV_COLOR_16_SWAP of the buffers                                                 */
+    uint8_t reserved[2];
+} lvgpu_blend_batch_t;
+
+int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Flush: the copy / rotate of lvgl_port_flush_callback over a batch of frames                                  */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * The pixel movement of lvgl_port_flush_callback (src/lv_port.c:428-572) for a flushed area of width x height
+ * LVGL pixels, with all its transport chunks concatenated in emission order (the chunks of one frame tile the
+ * panel image exactly, so the concatenation IS the panel image):
+ *   ROT_NONE: out[y*W + x]               = in[y*W + x]      (:533-538)
+ *   ROT_90  : out[x*H + (H-1-y)]         = in[y*W + x]      (:500-505)   panel image is H wide, W tall
+ *   ROT_180 : out[(H-1-y)*W + (W-1-x)]   = in[y*W + x]      (:522-527)
+ *   ROT_270 : out[(W-1-x)*H + y]         = in[y*W + x]      (:511-516)
+ * swap_bytes != 0 additionally byte-swaps every pixel on the way out: that is the conversion of a
+ * LV_COLOR_16_SWAP 0 draw buffer into the panel's big-endian wire order (src/display.h:26-30); with
+ * LV_COLOR_16_SWAP 1 buffers the reference has no swap pass and swap_bytes must be 0.
+ * in and out must not overlap.
+ */
+typedef struct {
+    const void * in;          /* device: n_frames rendered buffers, width*height lv_color_t each                 */
+    int64_t in_frame_stride;  /* pixels                                                                          */
+    void * out;               /* device: n_frames panel images, width*height pixels each                         */
+    int64_t out_frame_stride; /* pixels                                                                          */
+    int32_t width, height;    /* of the flushed area (LVGL logical orientation)                                  */
+    int32_t rotation;         /* LVGPU_ROT_*                                                                     */
+    int32_t swap_bytes;
+    int32_t n_frames;
+    int32_t reserved;
+} lvgpu_flush_batch_t;
+
+int lvgpu_flush_rotate_batch(const lvgpu_flush_batch_t * dsc, void * stream);
+
+/*
+ * Blend followed by the flush of the whole destination buffer (buf_area), in one pass over memory where the
+ * shapes allow it: the blended pixels are written back to dst (LVGL's draw buffer is mutated in place) AND written
+ * rotated to out.  Result == lvgpu_blend_batch(blend) then lvgpu_flush_rotate_batch({dst -> out, W = width(buf_area),
+ * H = height(buf_area)}).
+ */
+typedef struct {
+    lvgpu_blend_batch_t blend;
+    void * out;               /* device: n_frames panel images                                                   */
+    int64_t out_frame_stride; /* pixels                                                                          */
+    int32_t rotation;         /* LVGPU_ROT_*                                                                     */
+    int32_t swap_bytes;
+} lvgpu_blend_flush_batch_t;
+
+int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * dsc, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Colour conversion (libraries/lvgl/src/misc/lv_color.h)                                                       */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+/* lv_color_hex (:599-631) / lv_color_make (:594-597) over n pixels: 0x00RRGGBB words -> lv_color16_t. */
+int lvgpu_color_from_rgb888(const uint32_t * dev_xrgb, uint16_t * dev_out, size_t n, int color_16_swap, void * stream);
+/* lv_color_to32 (:374-427) over n pixels: lv_color16_t -> 0xFFRRGGBB words. */
+int lvgpu_color_to32(const uint16_t * dev_in, uint32_t * dev_out, size_t n, int color_16_swap, void * stream);
+/* The ARGB8888 -> (lv_color16_t, A8) split of lv_png.c:244-253 + lv_draw_sw_img.c:249-275 as a stand-alone pass.
+ * src_format is LVGPU_SRC_ARGB8888, LVGPU_SRC_RGBA8888 or LVGPU_SRC_ARGB8565. */
+int lvgpu_image_split(const void * dev_src, int src_format, uint16_t * dev_color, uint8_t * dev_alpha, size_t n,
+                      int color_16_swap, void * stream);
+/* lv_color_fill (libraries/lvgl/src/misc/lv_color.c:36-77). */
+int lvgpu_color_fill(uint16_t * dev_buf, uint16_t color, size_t n, void * stream);
+/* lv_draw_sw_buffer_copy (libraries/lvgl/src/draw/sw/lv_draw_sw.c:81-104) over n_frames buffers. */
+int lvgpu_buffer_copy_batch(void * dev_dst, int64_t dst_frame_stride, int32_t dst_stride, lvgpu_area_t dst_area,
+                            const void * dev_src, int64_t src_frame_stride, int32_t src_stride, lvgpu_area_t src_area,
+                            int32_t n_frames, void * stream);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Synthetic inputs and checksums (measurement support)                                                         */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+enum {
+    LVGPU_SYNTH_U16 = 0,      /* uniform lv_color16_t                                                            */
+    LVGPU_SYNTH_MASK_UI = 1,  /* A8: P(0)=1/3, P(255)=1/3, else uniform 1..254                                   */
+    LVGPU_SYNTH_MASK_UNI = 2, /* A8: uniform 0..255                                                              */
+    LVGPU_SYNTH_ARGB_UI = 3,  /* u32: uniform RGB, A from the UI-like mask distribution                          */
+    LVGPU_SYNTH_ARGB_UNI = 4  /* u32: uniform                                                                    */
+};
+/* Element i (global index first_index + i) is a pure function of (kind, seed, global index): counter-based
+ * splitmix64, identical to the CPU oracle's generator, so shards are reproducible for any frame partition. */
+int lvgpu_synth(void * dev_out, int kind, uint64_t seed, uint64_t first_index, size_t count, void * stream);
+/* Order-independent 64-bit checksum of n 16-bit (elem_bytes=2), 8-bit (1) or 32-bit (4) elements:
+ * sum over i of splitmix64(first_index + i, value_i) mod 2^64.  *dev_sum64 is ADDED to (zero it first). */
+int lvgpu_checksum(const void * dev_in, int elem_bytes, uint64_t first_index, size_t count, uint64_t * dev_sum64,
+                   void * stream);
+
+/* Name of the kernel the last launch on this thread used (diagnostics / tests that assert the fast path ran). */
+const char * lvgpu_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* LVGPU_H */
