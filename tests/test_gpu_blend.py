@@ -1,0 +1,154 @@
+"""GPU parity: lvgpu_blend_batch (through the C ABI) against the CPU oracle, bit-exact.
+
+Mirrors how the reference would test lv_draw_sw_blend: a draw context (buffer + buf_area + clip_area), a blend
+descriptor, and the resulting buffer compared byte for byte.
+"""
+import numpy as np
+import pytest
+
+from util import OPAS, rand_mask, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_frames(O, dst, buf_area, clip, blend_area, src, color, mask, mask_res, mask_area, opa, mode, swap, fmt=1,
+                   hor_res=480):
+    out = dst.copy()
+    for f in range(out.shape[0]):
+        s = None if src is None else (src if src.ndim == (2 if fmt != 4 else 3) else src[f])
+        m = None if mask is None else (mask if mask.ndim == 2 else mask[f])
+        if fmt in (0, 1):
+            O.blend(out[f], buf_area, clip, blend_area, src=s, color=color, mask=m, mask_res=mask_res,
+                    mask_area=mask_area, opa=opa, blend_mode=mode, swap=swap)
+        else:
+            # image with its own alpha: the oracle restates lv_draw_sw_img_decoded (chunked split + blend)
+            inter = O.Area()
+            if not O.lib().lvref_area_intersect(__import__("ctypes").byref(inter), __import__("ctypes").byref(
+                    O.Area.of(clip)), __import__("ctypes").byref(O.Area.of(blend_area))):
+                continue
+            O.img_blend(out[f], buf_area, inter.tup(), blend_area, np.ascontiguousarray(s), fmt, opa, swap, hor_res)
+    return out
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_blend_random_rects(gpu, oracle, swap):
+    """Clipped, misaligned rectangles; fill and map; every mask_res; opa across all thresholds (generic kernel)."""
+    rng = np.random.default_rng(100 + swap)
+    W, H, N = 67, 19, 3
+    buf_area = (0, 0, W - 1, H - 1)
+    for t in range(300):
+        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        if t % 3 == 0:
+            dst[rng.random(dst.shape) < 0.6] = 0
+        if t % 7 == 0:
+            dst[:, : H // 2] = 0
+        x1, y1 = int(rng.integers(-3, W - 2)), int(rng.integers(-2, H - 1))
+        x2, y2 = int(rng.integers(x1, W + 3)), int(rng.integers(y1, H + 2))
+        ba = (x1, y1, x2, y2)
+        cx1, cy1 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        clip = (cx1, cy1, int(rng.integers(cx1, W)), int(rng.integers(cy1, H)))
+        bw, bh = x2 - x1 + 1, y2 - y1 + 1
+        src = None
+        if rng.random() < 0.5:
+            src = rng.integers(0, 65536, (N, bh, bw) if rng.random() < 0.5 else (bh, bw), dtype=np.uint16)
+        ma = (x1 - int(rng.integers(0, 3)), y1 - int(rng.integers(0, 3)), x2 + int(rng.integers(0, 3)),
+              y2 + int(rng.integers(0, 3)))
+        mask = None
+        if rng.random() < 0.6:
+            shp = (ma[3] - ma[1] + 1, ma[2] - ma[0] + 1)
+            mask = rand_mask(rng, (N,) + shp if rng.random() < 0.5 else shp)
+        opa = int(rng.choice(OPAS))
+        mres = int(rng.choice([0, 1, 2, 2, 2, 3]))
+        color = int(rng.integers(0, 65536))
+        mode = 0
+        exp = _oracle_frames(oracle, dst, buf_area, clip, ba, src, color, mask, mres, ma, opa, mode, swap)
+
+        d = to_dev(dst)
+        ctx = gpu.DrawCtx(d, buf_area, clip, color_16_swap=swap)
+        dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), mask_res=mres, mask_area=ma, opa=opa,
+                           blend_mode=mode)
+        gpu.lv_draw_sw_blend(ctx, dsc)
+        got = to_np(d, np.uint16)
+        assert np.array_equal(got, exp), "trial %d opa %d mres %d src %s mask %s" % (t, opa, mres, src is not None,
+                                                                                      mask is not None)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("shape", [(480, 320), (320, 480), (64, 8), (8, 8), (72, 40)])
+def test_blend_full_frame_fast_path(gpu, oracle, swap, shape):
+    """Full-frame blends take the vectorised kernel; all fill/map branches and opa thresholds."""
+    W, H = shape
+    N = 3
+    rng = np.random.default_rng(7 + W + swap)
+    area = (0, 0, W - 1, H - 1)
+    cases = []
+    for opa in OPAS:
+        for has_src in (0, 1):
+            for has_mask in (0, 1):
+                cases.append((opa, has_src, has_mask))
+    for opa, has_src, has_mask in cases:
+        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        dst[0, : H // 2] = 0          # leading black
+        dst[1] = 0                    # all black
+        dst[2, H // 2:] = 0           # black after non-black
+        src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16) if has_src else None
+        mask = rand_mask(rng, (N, H, W)) if has_mask else None
+        color = int(rng.integers(0, 65536))
+        exp = _oracle_frames(oracle, dst, area, area, area, src, color, mask, 2, area, opa, 0, swap)
+        d = to_dev(dst)
+        ctx = gpu.DrawCtx(d, color_16_swap=swap)
+        dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), opa=opa)
+        gpu.lv_draw_sw_blend(ctx, dsc)
+        if opa > 2:
+            assert gpu.last_kernel() == "k_blend_linear"
+        got = to_np(d, np.uint16)
+        assert np.array_equal(got, exp), "opa %d src %d mask %d" % (opa, has_src, has_mask)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_blend_image_with_alpha(gpu, oracle, swap, fmt):
+    """ARGB8888 / RGBA8888 / ARGB8565 images: the colour/alpha split fused in front of map_normal (config 2)."""
+    rng = np.random.default_rng(55 + fmt + swap)
+    N = 2
+    for (W, H, clip, coords) in [(480, 320, None, None), (64, 24, (3, 2, 50, 20), (1, 1, 60, 22)),
+                                 (40, 16, (0, 0, 39, 15), (0, 0, 39, 15))]:
+        area = (0, 0, W - 1, H - 1)
+        clip = clip or area
+        coords = coords or area
+        iw, ih = coords[2] - coords[0] + 1, coords[3] - coords[1] + 1
+        for opa in (255, 254, 253, 252, 128, 3, 2):
+            dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            if fmt == 4:
+                src = rng.integers(0, 256, (N, ih, iw, 3), dtype=np.uint8)
+                src[..., 2] = rand_mask(rng, (N, ih, iw))
+            else:
+                src = rng.integers(0, 1 << 32, (N, ih, iw), dtype=np.uint32)
+                a = rand_mask(rng, (N, ih, iw)).astype(np.uint32)
+                src = (src & 0xFFFFFF) | (a << 24)
+            exp = _oracle_frames(oracle, dst, area, clip, coords, src, 0, None, 2, coords, opa, 0, swap, fmt=fmt,
+                                 hor_res=W)
+            d = to_dev(dst)
+            ctx = gpu.DrawCtx(d, area, clip, color_16_swap=swap)
+            dsc = gpu.BlendDsc(coords, src_buf=to_dev(src), opa=opa, src_format=fmt)
+            gpu.lv_draw_sw_blend(ctx, dsc)
+            got = to_np(d, np.uint16)
+            assert np.array_equal(got, exp), "fmt %d opa %d %dx%d" % (fmt, opa, W, H)
+
+
+def test_blend_noop_and_errors(gpu):
+    import torch
+    d = torch.zeros((2, 8, 8), dtype=torch.int16, device="cuda")
+    ctx = gpu.DrawCtx(d)
+    gpu.lv_draw_sw_blend(ctx, gpu.BlendDsc((20, 20, 30, 30), color=0xFFFF))          # outside the clip: no-op
+    gpu.lv_draw_sw_blend(ctx, gpu.BlendDsc((0, 0, 7, 7), color=0xFFFF, opa=2))       # opa <= LV_OPA_MIN: no-op
+    assert int(d.abs().sum()) == 0
+    bad = gpu.DrawCtx(d, clip_area=(0, 0, 20, 20))                                   # clip outside the buffer
+    with pytest.raises(gpu.LvgpuError):
+        gpu.lv_draw_sw_blend(bad, gpu.BlendDsc((0, 0, 20, 20), color=1))
+    with pytest.raises(gpu.LvgpuError):                                              # unknown source format
+        gpu.lv_draw_sw_blend(ctx, gpu.BlendDsc((0, 0, 7, 7), src_buf=d, src_format=9))
+    e = torch.zeros((0, 8, 8), dtype=torch.int16, device="cuda")                     # empty batch
+    gpu.lv_draw_sw_blend(gpu.DrawCtx(e), gpu.BlendDsc((0, 0, 7, 7), color=1))

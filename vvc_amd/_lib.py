@@ -1,0 +1,139 @@
+"""Loader for liblvgpu.so (built in-tree by vvc_amd/csrc/Makefile).  There is no fallback of any kind: if the
+library is missing or a symbol of include/lvgpu.h is absent, importing fails loudly."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblvgpu.so")
+HEADERS = [os.path.join(_HERE, "..", "include", "lvgpu.h"), os.path.join(_HERE, "..", "include", "lvgpu_lvgl.h")]
+
+
+class Area(C.Structure):
+    """lvgpu_area_t == lv_area_t (libraries/lvgl/src/misc/lv_area.h:43-48)."""
+    _fields_ = [("x1", C.c_int16), ("y1", C.c_int16), ("x2", C.c_int16), ("y2", C.c_int16)]
+
+    @classmethod
+    def of(cls, a):
+        if isinstance(a, cls):
+            return a
+        x1, y1, x2, y2 = a
+        return cls(int(x1), int(y1), int(x2), int(y2))
+
+    @property
+    def w(self):
+        return self.x2 - self.x1 + 1
+
+    @property
+    def h(self):
+        return self.y2 - self.y1 + 1
+
+    def tup(self):
+        return (self.x1, self.y1, self.x2, self.y2)
+
+
+class BlendBatch(C.Structure):
+    """lvgpu_blend_batch_t"""
+    _fields_ = [
+        ("dst", C.c_void_p), ("dst_frame_stride", C.c_int64),
+        ("buf_area", Area), ("clip_area", Area), ("blend_area", Area),
+        ("src", C.c_void_p), ("src_frame_stride", C.c_int64),
+        ("mask", C.c_void_p), ("mask_frame_stride", C.c_int64), ("mask_area", Area),
+        ("n_frames", C.c_int32), ("src_format", C.c_int32),
+        ("color", C.c_uint16), ("mask_res", C.c_uint8), ("opa", C.c_uint8),
+        ("blend_mode", C.c_uint8), ("color_16_swap", C.c_uint8), ("reserved", C.c_uint8 * 2),
+    ]
+
+
+class FlushBatch(C.Structure):
+    """lvgpu_flush_batch_t"""
+    _fields_ = [
+        ("inp", C.c_void_p), ("in_frame_stride", C.c_int64),
+        ("out", C.c_void_p), ("out_frame_stride", C.c_int64),
+        ("width", C.c_int32), ("height", C.c_int32), ("rotation", C.c_int32), ("swap_bytes", C.c_int32),
+        ("n_frames", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class BlendFlushBatch(C.Structure):
+    """lvgpu_blend_flush_batch_t"""
+    _fields_ = [("blend", BlendBatch), ("out", C.c_void_p), ("out_frame_stride", C.c_int64),
+                ("rotation", C.c_int32), ("swap_bytes", C.c_int32)]
+
+
+def declared_symbols():
+    """Every function name declared in include/*.h (used by the tests to check the export table)."""
+    names = []
+    for h in HEADERS:
+        if not os.path.exists(h):
+            continue
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(lvgpu_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblvgpu.so not found at %s -- build it with `make -C vvc_amd/csrc` (hipcc, gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+    sig = {
+        "lvgpu_init": (C.c_int, [C.c_int]),
+        "lvgpu_version": (C.c_int, []),
+        "lvgpu_last_error": (C.c_char_p, []),
+        "lvgpu_last_kernel": (C.c_char_p, []),
+        "lvgpu_device_count": (C.c_int, []),
+        "lvgpu_malloc": (C.c_int, [C.POINTER(vp), sz]),
+        "lvgpu_free": (C.c_int, [vp]),
+        "lvgpu_memcpy_h2d": (C.c_int, [vp, vp, sz, vp]),
+        "lvgpu_memcpy_d2h": (C.c_int, [vp, vp, sz, vp]),
+        "lvgpu_memset": (C.c_int, [vp, C.c_int, sz, vp]),
+        "lvgpu_stream_synchronize": (C.c_int, [vp]),
+        "lvgpu_blend_batch": (C.c_int, [C.POINTER(BlendBatch), vp]),
+        "lvgpu_flush_rotate_batch": (C.c_int, [C.POINTER(FlushBatch), vp]),
+        "lvgpu_blend_flush_batch": (C.c_int, [C.POINTER(BlendFlushBatch), vp]),
+        "lvgpu_color_from_rgb888": (C.c_int, [vp, vp, sz, C.c_int, vp]),
+        "lvgpu_color_to32": (C.c_int, [vp, vp, sz, C.c_int, vp]),
+        "lvgpu_image_split": (C.c_int, [vp, C.c_int, vp, vp, sz, C.c_int, vp]),
+        "lvgpu_color_fill": (C.c_int, [vp, C.c_uint16, sz, vp]),
+        "lvgpu_buffer_copy_batch": (C.c_int, [vp, i64, i32, Area, vp, i64, i32, Area, i32, vp]),
+        "lvgpu_synth": (C.c_int, [vp, C.c_int, u64, u64, sz, vp]),
+        "lvgpu_checksum": (C.c_int, [vp, C.c_int, u64, sz, vp, vp]),
+        "lvgpu_lvgl_bind": (None, [vp, vp, vp]),
+        "lvgpu_lvgl_set_color_16_swap": (None, [C.c_int]),
+        "lvgpu_draw_ctx_init": (None, [vp, vp]),
+        "lvgpu_draw_ctx_deinit": (None, [vp, vp]),
+        "lvgpu_draw_ctx_size": (sz, []),
+        "lvgpu_blend": (None, [vp, vp]),
+        "lvgpu_wait_for_finish": (None, [vp]),
+        "lvgpu_flush_cb": (None, [vp, vp, vp]),
+        "lvgpu_lvgl_get_stats": (None, [vp]),
+        "lvgpu_lvgl_reset_stats": (None, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class LvgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lvgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise LvgpuError(rc, lib().lvgpu_last_error().decode())
+    return rc

@@ -1,0 +1,511 @@
+// lvgpu.hip -- C ABI of liblvgpu.so (see include/lvgpu.h): argument checking, the control logic of
+// lv_draw_sw_blend / lv_draw_sw_blend_basic (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:95-204) resolved on the
+// host into kernel arguments, and kernel selection.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/lvgpu.h"
+#include "lvgpu_kernels.hpp"
+
+using namespace lvgpu;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local const char * g_last_kernel = "";
+
+int fail(int code, const char * fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if(e_ != hipSuccess) return fail(LVGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while(0)
+
+inline int aw(const lvgpu_area_t & a) { return a.x2 - a.x1 + 1; }
+inline int ah(const lvgpu_area_t & a) { return a.y2 - a.y1 + 1; }
+inline bool intersect(lvgpu_area_t & r, const lvgpu_area_t & a, const lvgpu_area_t & b)  // lv_area.c:129-144
+{
+    r.x1 = a.x1 > b.x1 ? a.x1 : b.x1;
+    r.y1 = a.y1 > b.y1 ? a.y1 : b.y1;
+    r.x2 = a.x2 < b.x2 ? a.x2 : b.x2;
+    r.y2 = a.y2 < b.y2 ? a.y2 : b.y2;
+    return !(r.x1 > r.x2 || r.y1 > r.y2);
+}
+inline uint32_t bswap16(uint32_t v) { return ((v << 8) | (v >> 8)) & 0xFFFFu; }
+inline uint32_t host_mix(uint32_t fg, uint32_t bg, uint32_t mix)  // native values; lv_color.h:447-453
+{
+    uint32_t m5 = (mix + 4) >> 3;
+    uint32_t b = (bg | (bg << 16)) & 0x07E0F81Fu, f = (fg | (fg << 16)) & 0x07E0F81Fu;
+    uint32_t r = ((((f - b) * m5) >> 5) + b) & 0x07E0F81Fu;
+    return ((r >> 16) | r) & 0xFFFFu;
+}
+inline bool aligned(const void * p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+int src_bytes_per_px(int fmt)
+{
+    switch(fmt) {
+        case LVGPU_SRC_RGB565: return 2;
+        case LVGPU_SRC_ARGB8888:
+        case LVGPU_SRC_RGBA8888: return 4;
+        case LVGPU_SRC_ARGB8565: return 3;
+        default: return 0;
+    }
+}
+
+enum Resolve { R_NOOP = 0, R_WORK = 1 };
+
+// lv_draw_sw_blend (:95-106) + lv_draw_sw_blend_basic (:108-204) up to the fill_normal/map_normal dispatch.
+// Returns R_NOOP / R_WORK or a negative error; on R_WORK `a` describes the clipped area.
+int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & area)
+{
+    memset(&a, 0, sizeof(a));
+    if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
+    if(d->n_frames < 0) return fail(LVGPU_ERR_ARG, "n_frames < 0");
+    if(d->n_frames == 0) return R_NOOP;
+    if(d->dst == nullptr) return fail(LVGPU_ERR_ARG, "dst is NULL");
+    if(d->src_format < LVGPU_SRC_FILL || d->src_format > LVGPU_SRC_ARGB8565)
+        return fail(LVGPU_ERR_ARG, "bad src_format %d", d->src_format);
+    if(d->src_format != LVGPU_SRC_FILL && d->src == nullptr) return fail(LVGPU_ERR_ARG, "src is NULL");
+    if(aw(d->buf_area) <= 0 || ah(d->buf_area) <= 0) return fail(LVGPU_ERR_ARG, "empty buf_area");
+    const bool own_alpha = d->src_format >= LVGPU_SRC_ARGB8888;
+    if(own_alpha && d->mask) return fail(LVGPU_ERR_UNSUPPORTED, "a mask on top of a source with its own alpha");
+    if(d->blend_mode > LVGPU_BLEND_REPLACE) return fail(LVGPU_ERR_ARG, "bad blend_mode %d", d->blend_mode);
+
+    if(d->opa <= 2) return R_NOOP;                                            // :98  LV_OPA_MIN
+    if(!intersect(area, d->blend_area, d->clip_area)) return R_NOOP;          // :101
+    // The reference trusts clip_area to lie inside buf_area; a GPU write outside the buffer is not acceptable.
+    if(area.x1 < d->buf_area.x1 || area.y1 < d->buf_area.y1 || area.x2 > d->buf_area.x2 || area.y2 > d->buf_area.y2)
+        return fail(LVGPU_ERR_ARG, "clip_area reaches outside buf_area");
+
+    const uint8_t * mask = d->mask;
+    uint8_t mask_res = d->mask_res;
+    if(own_alpha) mask_res = LVGPU_MASK_RES_CHANGED;                          // lv_draw_sw_img.c:133-136
+    if(!own_alpha) {
+        if(mask && mask_res == LVGPU_MASK_RES_TRANSP) return R_NOOP;          // :113
+        else if(mask_res == LVGPU_MASK_RES_FULL_COVER) mask = nullptr;        // :114
+    }
+    const bool masked = own_alpha || mask != nullptr;
+    if(mask) {
+        if(area.x1 < d->mask_area.x1 || area.y1 < d->mask_area.y1 || area.x2 > d->mask_area.x2 ||
+           area.y2 > d->mask_area.y2)
+            return fail(LVGPU_ERR_ARG, "mask_area does not cover the clipped blend area");
+    }
+
+    a.dst_stride = aw(d->buf_area);                                           // :117
+    a.dst_fs = d->dst_frame_stride;
+    a.dst = reinterpret_cast<uint16_t *>(d->dst) +
+            (size_t)a.dst_stride * (area.y1 - d->buf_area.y1) + (area.x1 - d->buf_area.x1);   // :126
+    a.w = aw(area);
+    a.h = ah(area);
+    a.n_frames = d->n_frames;
+    a.swap = d->color_16_swap ? 1 : 0;
+    a.opa = d->opa;
+    if(d->src_format != LVGPU_SRC_FILL) {
+        a.src_stride = aw(d->blend_area);                                     // :140
+        a.src_fs = d->src_frame_stride;
+        size_t ofs = (size_t)a.src_stride * (area.y1 - d->blend_area.y1) + (area.x1 - d->blend_area.x1);   // :141
+        a.src = reinterpret_cast<const uint8_t *>(d->src) + ofs * src_bytes_per_px(d->src_format);
+    }
+    if(mask) {
+        a.mask_stride = aw(d->mask_area);                                     // :158
+        a.mask_fs = d->mask_frame_stride;
+        a.mask = mask + (size_t)a.mask_stride * (area.y1 - d->mask_area.y1) + (area.x1 - d->mask_area.x1);   // :159
+    }
+    a.color = a.swap ? bswap16(d->color) : d->color;
+
+    const bool fill = d->src_format == LVGPU_SRC_FILL;
+    if(d->blend_mode == LVGPU_BLEND_NORMAL) {                                 // :186-193
+        a.blend_fn = BF_NORMAL;
+        if(!masked) {
+            if(d->opa >= 253) {                                               // fill :254-259, map :655-660
+                a.opa_mode = OM_CONST;
+                a.opa = 255;
+            }
+            else if(fill) {                                                   // :261-287
+                a.opa_mode = OM_FILL_PREMULT;
+                const uint32_t opa_q = ((((uint32_t)d->opa + 4) >> 3) << 3) & 0xFFu;   // uint8 wrap: 252 -> 0
+                const uint32_t c = a.color;
+                a.pf.pm_r = (c >> 11) * opa_q;
+                a.pf.pm_g = ((c >> 5) & 0x3Fu) * opa_q;
+                a.pf.pm_b = (c & 0x1Fu) * opa_q;
+                a.pf.opa_inv = 255u - opa_q;
+                a.pf.first_res = host_mix(c, 0, d->opa);
+            }
+            else a.opa_mode = OM_CONST;                                       // :662-670
+        }
+        else if(fill) a.opa_mode = d->opa >= 253 ? OM_MASK : OM_FILL_MASK_OPA;   // :295 / :346
+        else a.opa_mode = d->opa > 253 ? OM_MASK : OM_MAP_MASK_OPA;           // :675 (strict) / :720
+    }
+    else if(d->blend_mode <= LVGPU_BLEND_MULTIPLY) {                          // :194-203, fill_blended / map_blended
+        a.blend_fn = d->blend_mode;
+        a.opa_mode = masked ? OM_MAP_MASK_OPA : OM_CONST;                     // :583/:590, :929/:934
+    }
+    else return R_NOOP;  // "unsupported blend mode": the reference logs a warning and draws nothing (:556-558)
+    return R_WORK;
+}
+
+// min index of the first non-black pixel per frame, only needed when the two formulas of the translucent fill
+// disagree on black (otherwise every black pixel gets the same value either way).
+int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** scratch)
+{
+    *scratch = nullptr;
+    if(a.opa_mode != OM_FILL_PREMULT) return LVGPU_OK;
+    const uint32_t pm_black = ((((a.pf.pm_r * 0x8081u) >> 23) & 0x1Fu) << 11) | ((((a.pf.pm_g * 0x8081u) >> 23) & 0x3Fu) << 5) |
+                              (((a.pf.pm_b * 0x8081u) >> 23) & 0x1Fu);
+    if(pm_black == a.pf.first_res) return LVGPU_OK;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(scratch), (size_t)a.n_frames * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(*scratch, 0xFF, (size_t)a.n_frames * sizeof(uint32_t), st));
+    const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+    dim3 grid(std::min<uint32_t>((area + 255) / 256, 64), std::min<uint32_t>(a.n_frames, 65535));
+    hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, *scratch);
+    HIP_TRY(hipGetLastError());
+    a.first_nb = *scratch;
+    return LVGPU_OK;
+}
+
+template <template <int> class L, typename... Args>
+int dispatch_src(int fmt, Args &&... args)
+{
+    switch(fmt) {
+        case SRC_FILL: return L<SRC_FILL>::run(args...);
+        case SRC_RGB565: return L<SRC_RGB565>::run(args...);
+        case SRC_ARGB8888: return L<SRC_ARGB8888>::run(args...);
+        case SRC_RGBA8888: return L<SRC_RGBA8888>::run(args...);
+        case SRC_ARGB8565: return L<SRC_ARGB8565>::run(args...);
+        default: return L<SRC_COPY>::run(args...);
+    }
+}
+
+template <int SRC>
+struct LaunchLinear {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const uint32_t gpf = (uint32_t)(((size_t)a.w * a.h) / 8);
+        const uint32_t cpf = (gpf + LIN_CHUNK - 1) / LIN_CHUNK;
+        const uint64_t blocks = (uint64_t)cpf * a.n_frames;
+        if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_blend_linear<SRC>, dim3((uint32_t)blocks), dim3(256), 0, st, a, gpf, cpf);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+template <int SRC>
+struct LaunchTile {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const int W = a.w, H = a.h;
+        const uint32_t tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+        const uint32_t tpf = tiles_x * tiles_y;
+        const uint64_t n_tiles = (uint64_t)tpf * a.n_frames;
+        if(n_tiles > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, st, a, W, H, tiles_x, tpf,
+                           (uint32_t)n_tiles);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+template <int SRC>
+struct LaunchGeneric {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+        dim3 grid((area + 255) / 256, std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_blend_generic<SRC>, grid, dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+
+// Can the clipped area of every frame be walked as one contiguous, 16-byte aligned run of 8-pixel groups?
+bool linear_ok(const BlendArgs & a, int fmt)
+{
+    if(((size_t)a.w * a.h) % 8) return false;
+    if(a.h > 1 && a.dst_stride != a.w) return false;
+    if(!aligned(a.dst, 16) || (a.dst_fs % 8)) return false;
+    if(fmt != SRC_FILL && fmt != SRC_COPY) {
+        if(a.h > 1 && a.src_stride != a.w) return false;
+        const size_t bpp = src_bytes_per_px(fmt);
+        const size_t al = fmt == SRC_ARGB8565 ? 8 : 16;
+        if(!aligned(a.src, al) || ((a.src_fs * bpp) % al)) return false;
+    }
+    if(a.mask) {
+        if(a.h > 1 && a.mask_stride != a.w) return false;
+        if(!aligned(a.mask, 8) || (a.mask_fs % 8)) return false;
+    }
+    return true;
+}
+// ... and additionally as whole W x H frames for the tile kernel (row starts stay 16-byte aligned).
+bool tile_ok(const BlendArgs & a, int fmt)
+{
+    return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
+}
+
+int launch_blend(BlendArgs & a, int fmt, hipStream_t st)
+{
+    uint32_t * scratch = nullptr;
+    int rc = prepare_first_nb(a, st, &scratch);
+    if(rc != LVGPU_OK) return rc;
+    if(linear_ok(a, fmt)) {
+        g_last_kernel = "k_blend_linear";
+        rc = dispatch_src<LaunchLinear>(fmt, a, st);
+    }
+    else {
+        g_last_kernel = "k_blend_generic";
+        rc = dispatch_src<LaunchGeneric>(fmt, a, st);
+    }
+    if(scratch) HIP_TRY(hipFreeAsync(scratch, st));
+    return rc;
+}
+
+int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs, int W, int H, int rot,
+                  int swap_out, int n_frames, hipStream_t st)
+{
+    BlendArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dst = const_cast<uint16_t *>(in);
+    a.dst_fs = in_fs;
+    a.dst_stride = W;
+    a.w = W;
+    a.h = H;
+    a.n_frames = n_frames;
+    a.out = out;
+    a.out_fs = out_fs;
+    a.rot = rot;
+    a.swap_out = swap_out ? 1 : 0;
+    const bool out_ok = aligned(out, 16) && (out_fs % 8) == 0;
+    const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
+    if(out_ok && transposing && tile_ok(a, SRC_COPY)) {
+        g_last_kernel = "k_tile";
+        return LaunchTile<SRC_COPY>::run(a, st);
+    }
+    if(out_ok && !transposing && linear_ok(a, SRC_COPY)) {
+        g_last_kernel = "k_blend_linear";
+        return LaunchLinear<SRC_COPY>::run(a, st);
+    }
+    g_last_kernel = "k_rotate_generic";
+    const uint32_t area = (uint32_t)W * (uint32_t)H;
+    dim3 grid((area + 255) / 256, std::min<uint32_t>(n_frames, 65535));
+    hipLaunchKernelGGL(k_rotate_generic, grid, dim3(256), 0, st, in, in_fs, out, out_fs, W, H, rot, swap_out ? 1 : 0, n_frames);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+
+inline dim3 stream_grid(size_t n)
+{
+    size_t b = (n + 255) / 256;
+    return dim3((uint32_t)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16));
+}
+
+}  // namespace
+
+extern "C" {
+
+int lvgpu_version(void) { return LVGPU_VERSION; }
+const char * lvgpu_last_error(void) { return g_err.c_str(); }
+const char * lvgpu_last_kernel(void) { return g_last_kernel; }
+
+int lvgpu_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lvgpu_init(int device)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(LVGPU_ERR_NO_DEVICE, "no HIP device visible");
+    if(device < 0 || device >= n) return fail(LVGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if(strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LVGPU_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    HIP_TRY(hipFree(nullptr));
+    return LVGPU_OK;
+}
+
+int lvgpu_malloc(void ** p, size_t bytes)
+{
+    if(!p) return fail(LVGPU_ERR_ARG, "NULL out pointer");
+    HIP_TRY(hipMalloc(p, bytes));
+    return LVGPU_OK;
+}
+int lvgpu_free(void * p)
+{
+    HIP_TRY(hipFree(p));
+    return LVGPU_OK;
+}
+int lvgpu_memcpy_h2d(void * d, const void * s, size_t n, void * stream)
+{
+    HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return LVGPU_OK;
+}
+int lvgpu_memcpy_d2h(void * d, const void * s, size_t n, void * stream)
+{
+    HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return LVGPU_OK;
+}
+int lvgpu_memset(void * d, int v, size_t n, void * stream)
+{
+    HIP_TRY(hipMemsetAsync(d, v, n, (hipStream_t)stream));
+    return LVGPU_OK;
+}
+int lvgpu_stream_synchronize(void * stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return LVGPU_OK;
+}
+
+int lvgpu_blend_batch(const lvgpu_blend_batch_t * d, void * stream)
+{
+    BlendArgs a;
+    lvgpu_area_t area;
+    g_last_kernel = "";
+    int r = resolve_blend(d, a, area);
+    if(r <= 0) return r;
+    return launch_blend(a, d->src_format, (hipStream_t)stream);
+}
+
+int lvgpu_flush_rotate_batch(const lvgpu_flush_batch_t * d, void * stream)
+{
+    g_last_kernel = "";
+    if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
+    if(d->n_frames < 0 || d->width <= 0 || d->height <= 0) return fail(LVGPU_ERR_ARG, "bad geometry");
+    if(d->rotation < LVGPU_ROT_NONE || d->rotation > LVGPU_ROT_270) return fail(LVGPU_ERR_ARG, "bad rotation %d", d->rotation);
+    if(d->n_frames == 0) return LVGPU_OK;
+    if(d->in == nullptr || d->out == nullptr) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    if((uint64_t)d->width * d->height > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "frame too large");
+    return launch_rotate(reinterpret_cast<const uint16_t *>(d->in), d->in_frame_stride, reinterpret_cast<uint16_t *>(d->out),
+                         d->out_frame_stride, d->width, d->height, d->rotation, d->swap_bytes, d->n_frames, (hipStream_t)stream);
+}
+
+int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
+{
+    g_last_kernel = "";
+    if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
+    if(d->out == nullptr) return fail(LVGPU_ERR_ARG, "out is NULL");
+    if(d->rotation < LVGPU_ROT_NONE || d->rotation > LVGPU_ROT_270) return fail(LVGPU_ERR_ARG, "bad rotation %d", d->rotation);
+    hipStream_t st = (hipStream_t)stream;
+    BlendArgs a;
+    lvgpu_area_t area;
+    int r = resolve_blend(&d->blend, a, area);
+    if(r < 0) return r;
+    const lvgpu_blend_batch_t & b = d->blend;
+    const int W = aw(b.buf_area), H = ah(b.buf_area);
+    if(b.n_frames == 0) return LVGPU_OK;
+    const bool transposing = d->rotation == LVGPU_ROT_90 || d->rotation == LVGPU_ROT_270;
+    const bool out_ok = aligned(d->out, 16) && (d->out_frame_stride % 8) == 0;
+    if(r == R_WORK && out_ok && a.w == W && a.h == H) {  // the blend touches the whole buffer: one pass over memory
+        a.out = reinterpret_cast<uint16_t *>(d->out);
+        a.out_fs = d->out_frame_stride;
+        a.rot = d->rotation;
+        a.swap_out = d->swap_bytes ? 1 : 0;
+        const bool ok = transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format);
+        if(ok) {
+            uint32_t * scratch = nullptr;
+            int rc = prepare_first_nb(a, st, &scratch);
+            if(rc != LVGPU_OK) return rc;
+            if(transposing) {
+                g_last_kernel = "k_tile(fused)";
+                rc = dispatch_src<LaunchTile>(b.src_format, a, st);
+            }
+            else {
+                g_last_kernel = "k_blend_linear(fused)";
+                rc = dispatch_src<LaunchLinear>(b.src_format, a, st);
+            }
+            if(scratch) HIP_TRY(hipFreeAsync(scratch, st));
+            return rc;
+        }
+        a.out = nullptr;
+    }
+    if(r == R_WORK) {
+        int rc = launch_blend(a, b.src_format, st);
+        if(rc != LVGPU_OK) return rc;
+    }
+    return launch_rotate(reinterpret_cast<const uint16_t *>(b.dst), b.dst_frame_stride, reinterpret_cast<uint16_t *>(d->out),
+                         d->out_frame_stride, W, H, d->rotation, d->swap_bytes, b.n_frames, st);
+}
+
+int lvgpu_color_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!in || !out) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    hipLaunchKernelGGL(k_from_rgb888, stream_grid(n), dim3(256), 0, (hipStream_t)stream, in, out, n, swap ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+int lvgpu_color_to32(const uint16_t * in, uint32_t * out, size_t n, int swap, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!in || !out) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    hipLaunchKernelGGL(k_to32, stream_grid(n), dim3(256), 0, (hipStream_t)stream, in, out, n, swap ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+int lvgpu_image_split(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!src || !color || !alpha) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    if(fmt < LVGPU_SRC_ARGB8888 || fmt > LVGPU_SRC_ARGB8565) return fail(LVGPU_ERR_ARG, "bad src_format %d", fmt);
+    hipLaunchKernelGGL(k_image_split, stream_grid(n), dim3(256), 0, (hipStream_t)stream, src, fmt, color, alpha, n, swap ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+int lvgpu_color_fill(uint16_t * buf, uint16_t color, size_t n, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!buf) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    hipLaunchKernelGGL(k_fill16, stream_grid(n), dim3(256), 0, (hipStream_t)stream, buf, color, n);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+int lvgpu_buffer_copy_batch(void * dst, int64_t dst_fs, int32_t dst_stride, lvgpu_area_t da, const void * src, int64_t src_fs,
+                            int32_t src_stride, lvgpu_area_t sa, int32_t n_frames, void * stream)
+{
+    if(n_frames == 0) return LVGPU_OK;
+    if(!dst || !src || n_frames < 0) return fail(LVGPU_ERR_ARG, "bad arguments");
+    const int w = aw(da), h = ah(da);  // lv_draw_sw.c:97-99: width and row count come from dest_area
+    if(w <= 0 || h <= 0) return LVGPU_OK;
+    uint16_t * dp = reinterpret_cast<uint16_t *>(dst) + (size_t)dst_stride * da.y1 + da.x1;         // :91-92
+    const uint16_t * sp = reinterpret_cast<const uint16_t *>(src) + (size_t)src_stride * sa.y1 + sa.x1;   // :94-95
+    dim3 grid(((uint32_t)w * h + 255) / 256, std::min<uint32_t>(n_frames, 65535));
+    hipLaunchKernelGGL(k_buffer_copy, grid, dim3(256), 0, (hipStream_t)stream, dp, dst_fs, dst_stride, sp, src_fs, src_stride, w, h,
+                       n_frames);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+
+int lvgpu_synth(void * out, int kind, uint64_t seed, uint64_t first, size_t n, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!out || kind < 0 || kind > 4) return fail(LVGPU_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(k_synth, stream_grid(n), dim3(256), 0, (hipStream_t)stream, out, kind, seed, first, n);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+int lvgpu_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, uint64_t * sum, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!in || !sum || (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)) return fail(LVGPU_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(k_checksum, stream_grid(n), dim3(256), 0, (hipStream_t)stream, in, elem_bytes, first, n,
+                       reinterpret_cast<unsigned long long *>(sum));
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// lvgpu_kernels.hpp -- HIP kernels (gfx950) for the batched LVGL pixel path.
+//
+// Data layout in HBM: every frame is a row-major array of 2-byte pixels, frames lie `*_fs` pixels apart.  All fast
+// kernels move 16 bytes of destination pixels (8 px) per lane per access; a wavefront (64 lanes) therefore
+// touches whole 128-byte lines.  There is no reuse between pixels, so the kernels are pure HBM streams:
+//   k_blend_linear : blend (+ optional un-rotated / 180-degree output) over areas that are contiguous in memory
+//   k_tile         : blend and/or 90/270-degree rotation; a wave owns a 64x64-pixel tile, each lane an 8x8 block,
+//                    transposes it in registers and exchanges it through wave-private LDS so that both the loads
+//                    and the rotated stores are 128-byte contiguous per 8 lanes
+//   k_blend_generic / k_rotate_generic : one pixel per lane, any geometry or alignment
+#pragma once
+#include "lvgpu_px.hpp"
+
+namespace lvgpu {
+
+struct BlendArgs {
+    uint16_t * dst;        // first pixel of the (clipped) area in frame 0
+    long long dst_fs;      // frame stride, pixels
+    int dst_stride;        // row stride, pixels
+    const void * src;      // first source pixel of the area in frame 0 (format per template parameter)
+    long long src_fs;      // source pixels
+    int src_stride;
+    const uint8_t * mask;  // first mask byte of the area in frame 0, or nullptr
+    long long mask_fs;     // bytes
+    int mask_stride;
+    int w, h;              // area size
+    int n_frames;
+    uint32_t color;        // native fill colour
+    uint32_t opa;
+    int opa_mode;          // OpaMode
+    int blend_fn;          // BlendFn
+    int swap;              // LV_COLOR_16_SWAP of dst/src
+    PremultFill pf;
+    const uint32_t * first_nb;  // per frame: scan index of the first non-black pixel (OM_FILL_PREMULT), or nullptr
+    uint16_t * out;        // rotated / copied output (frame 0), or nullptr
+    long long out_fs;
+    int rot;               // LVGPU_ROT_*
+    int swap_out;          // byte-swap pixels written to out
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// one pixel
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t px_core(const BlendArgs & a, uint32_t d, uint32_t fg, uint32_t m,
+                                            uint32_t scan_idx, uint32_t fnb)
+{
+    uint32_t o;
+    switch(a.opa_mode) {
+        case OM_CONST: o = a.opa; break;
+        case OM_MASK: o = m; break;
+        case OM_FILL_MASK_OPA: o = px_opa<OM_FILL_MASK_OPA>(m, a.opa); break;
+        case OM_MAP_MASK_OPA: o = px_opa<OM_MAP_MASK_OPA>(m, a.opa); break;
+        default: return px_fill_premult(a.pf, d, scan_idx, fnb);
+    }
+    switch(a.blend_fn) {
+        case BF_ADDITIVE: fg = px_blend_fn<BF_ADDITIVE>(fg, d, a.swap); break;
+        case BF_SUBTRACTIVE: fg = px_blend_fn<BF_SUBTRACTIVE>(fg, d, a.swap); break;
+        case BF_MULTIPLY: fg = px_blend_fn<BF_MULTIPLY>(fg, d, a.swap); break;
+        default: break;
+    }
+    return px_mix(fg, d, o);
+}
+
+// Source pixel j (0..7) of an 8-pixel group held in registers: native colour + alpha.
+template <int SRC>
+__device__ __forceinline__ void src_px(const uint32_t * sw, int j, int swap, uint32_t & fg, uint32_t & alpha)
+{
+    if(SRC == SRC_RGB565) {
+        uint32_t v = (sw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+        fg = swap ? px_swap16(v) : v;
+    }
+    else if(SRC == SRC_ARGB8888) {
+        fg = px_from_argb8888(sw[j]);
+        alpha = sw[j] >> 24;
+    }
+    else if(SRC == SRC_RGBA8888) {
+        fg = px_from_rgba8888(sw[j]);
+        alpha = sw[j] >> 24;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const int byte = 3 * j, w0 = byte >> 2, sh = (byte & 3) * 8;
+        uint64_t two = (uint64_t)sw[w0] | ((uint64_t)sw[w0 + 1 < 6 ? w0 + 1 : 5] << 32);
+        uint32_t v = (uint32_t)(two >> sh);
+        uint32_t c = v & 0xFFFFu;
+        fg = swap ? px_swap16(c) : c;
+        alpha = (v >> 16) & 0xFFu;
+    }
+}
+
+template <int SRC>
+struct SrcWords {
+    static constexpr int N = SRC == SRC_RGB565 ? 4 : (SRC == SRC_ARGB8565 ? 6 : (SRC == SRC_FILL || SRC == SRC_COPY ? 1 : 8));
+};
+
+// Load the source words of the 8-pixel group that starts at source pixel index `px` (aligned by the launcher).
+template <int SRC>
+__device__ __forceinline__ void load_src(const void * base, long long px, uint32_t * sw)
+{
+    if(SRC == SRC_RGB565) {
+        uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(base) + px);
+        sw[0] = v.x; sw[1] = v.y; sw[2] = v.z; sw[3] = v.w;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        const uint4 * p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(base) + px);
+        uint4 v0 = p[0], v1 = p[1];
+        sw[0] = v0.x; sw[1] = v0.y; sw[2] = v0.z; sw[3] = v0.w;
+        sw[4] = v1.x; sw[5] = v1.y; sw[6] = v1.z; sw[7] = v1.w;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const uint2 * p = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(base) + px * 3);
+        uint2 v0 = p[0], v1 = p[1], v2 = p[2];
+        sw[0] = v0.x; sw[1] = v0.y; sw[2] = v1.x; sw[3] = v1.y; sw[4] = v2.x; sw[5] = v2.y;
+    }
+}
+
+// Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
+template <int SRC>
+__device__ __forceinline__ uint4 blend_group(const BlendArgs & a, uint4 d, const uint32_t * sw, uint2 mk,
+                                             uint32_t scan0, uint32_t fnb)
+{
+    uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+    if(a.swap) {
+#pragma unroll
+        for(int i = 0; i < 4; i++) dw[i] = px_swap16x2(dw[i]);
+    }
+    uint32_t rw[4];
+#pragma unroll
+    for(int j = 0; j < 8; j++) {
+        uint32_t dn = (dw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+        uint32_t fg = a.color;
+        uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
+        src_px<SRC>(sw, j, a.swap, fg, m);
+        uint32_t r = px_core(a, dn, fg, m, scan0 + (uint32_t)j, fnb);
+        if(j & 1) rw[j >> 1] |= r << 16;
+        else rw[j >> 1] = r;
+    }
+    if(a.swap) {
+#pragma unroll
+        for(int i = 0; i < 4; i++) rw[i] = px_swap16x2(rw[i]);
+    }
+    return make_uint4(rw[0], rw[1], rw[2], rw[3]);
+}
+
+__device__ __forceinline__ uint4 swap_group(uint4 v)
+{
+    return make_uint4(px_swap16x2(v.x), px_swap16x2(v.y), px_swap16x2(v.z), px_swap16x2(v.w));
+}
+// reverse the order of the 8 pixels of a group
+__device__ __forceinline__ uint4 reverse_group(uint4 v)
+{
+    auto r = [](uint32_t x) { return (x << 16) | (x >> 16); };
+    return make_uint4(r(v.w), r(v.z), r(v.y), r(v.x));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_blend_linear: the area of every frame is one contiguous run of gpf groups of 8 pixels.
+// Block b handles chunk (b % cpf) of frame (b / cpf): LIN_UNROLL groups per lane, loads first, then math, stores.
+// out (optional): rot NONE -> same order; rot 180 -> whole-frame reversal (src/lv_port.c:522-527, :533-538).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LIN_UNROLL = 4;
+constexpr int LIN_CHUNK = 256 * LIN_UNROLL;  // groups per block
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf, uint32_t cpf)
+{
+    const uint32_t f = blockIdx.x / cpf;
+    const uint32_t c = blockIdx.x - f * cpf;
+    uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+    const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+    const long long src_px0 = (long long)f * a.src_fs;
+    const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+    const uint32_t g0 = c * LIN_CHUNK + threadIdx.x;
+
+    uint4 d[LIN_UNROLL];
+    uint2 mk[LIN_UNROLL];
+    uint32_t sw[LIN_UNROLL][SrcWords<SRC>::N];
+    constexpr bool BLEND = SRC != SRC_COPY;
+#pragma unroll
+    for(int u = 0; u < LIN_UNROLL; u++) {
+        const uint32_t g = g0 + u * 256;
+        mk[u] = make_uint2(0, 0);
+        if(g < gpf) {
+            d[u] = *reinterpret_cast<const uint4 *>(dst + (size_t)g * 8);
+            if(BLEND) {
+                if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)g * 8, sw[u]);
+                if(mask) mk[u] = *reinterpret_cast<const uint2 *>(mask + (size_t)g * 8);
+            }
+        }
+    }
+#pragma unroll
+    for(int u = 0; u < LIN_UNROLL; u++) {
+        const uint32_t g = g0 + u * 256;
+        if(g < gpf) {
+            uint4 r = d[u];
+            if(BLEND) {
+                r = blend_group<SRC>(a, d[u], sw[u], mk[u], g * 8, fnb);
+                *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
+            }
+            if(a.out) {
+                uint16_t * out = a.out + (long long)f * a.out_fs;
+                if(a.swap_out) r = swap_group(r);
+                if(a.rot == 2) *reinterpret_cast<uint4 *>(out + (size_t)(gpf - 1 - g) * 8) = reverse_group(r);
+                else *reinterpret_cast<uint4 *>(out + (size_t)g * 8) = r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_tile: whole frames of W x H pixels (W % 8 == 0, H % 8 == 0), optional blend, 90/270-degree output.
+//   ROT_90 : out[x*H + (H-1-y)] = px(x,y)      (src/lv_port.c:500-505)
+//   ROT_270: out[(W-1-x)*H + y] = px(x,y)      (src/lv_port.c:511-516)
+// A wave owns tile (tx,ty) of 64x64 px; lane l owns the 8x8 block (bx = l&7, by = l>>3).  It loads 8 row
+// segments of 16 B (8 lanes = 128 B contiguous), blends, stores them back, transposes the block in registers
+// (one v_perm per output dword) and writes 8 column segments to the wave's 8 KB of LDS, XOR-swizzled so that
+// neither the 16-B writes nor the 16-B reads conflict.  After the exchange lane l holds, for k = 0..7, the segment
+// of output row (8k + l>>3) at 16-B chunk (l&7), so 8 consecutive lanes store 128 contiguous bytes.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TILE = 64;
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tpf, uint32_t n_tiles)
+{
+    __shared__ uint4 lds[4][512];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const bool live = wt < n_tiles;
+    const uint32_t f = live ? wt / tpf : 0;
+    const uint32_t t = live ? wt - f * tpf : 0;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    constexpr bool BLEND = SRC != SRC_COPY;
+
+    const int bx = lane & 7, by = lane >> 3;
+    const int x0 = tx * TILE + bx * 8, y0 = ty * TILE + by * 8;
+    const bool inside = live && x0 < W && y0 < H;
+
+    uint4 r[8];
+    if(inside) {
+        uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+        const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+        const long long src_px0 = (long long)f * a.src_fs;
+        const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+        uint4 d[8];
+        uint2 mk[8];
+        uint32_t sw[8][SrcWords<SRC>::N];
+#pragma unroll
+        for(int i = 0; i < 8; i++) {
+            const size_t p = (size_t)(y0 + i) * W + x0;
+            d[i] = *reinterpret_cast<const uint4 *>(dst + p);
+            mk[i] = make_uint2(0, 0);
+            if(BLEND) {
+                if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
+                if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
+            }
+        }
+#pragma unroll
+        for(int i = 0; i < 8; i++) {
+            r[i] = d[i];
+            if(BLEND) {
+                const size_t p = (size_t)(y0 + i) * W + x0;
+                r[i] = blend_group<SRC>(a, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                *reinterpret_cast<uint4 *>(dst + p) = r[i];
+            }
+            if(a.swap_out) r[i] = swap_group(r[i]);
+        }
+        // register transpose: column j of the block becomes an 8-pixel segment ordered along the output row
+        const bool r90 = a.rot == 1;
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+            uint32_t o[4];
+#pragma unroll
+            for(int m = 0; m < 4; m++) {
+                // output pixels 2m (low half) and 2m+1 (high half) of the segment
+                const uint4 & ra90 = r[7 - 2 * m], & rb90 = r[6 - 2 * m];
+                const uint4 & ra27 = r[2 * m], & rb27 = r[2 * m + 1];
+                auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
+                const uint32_t lo = r90 ? word(ra90) : word(ra27);
+                const uint32_t hi = r90 ? word(rb90) : word(rb27);
+                o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+            const int xl = bx * 8 + j;
+            lds[wave][xl * 8 + (by ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    if(live && a.out) {
+        uint16_t * out = a.out + (long long)f * a.out_fs;
+        const int rr = lane >> 3, c = lane & 7;
+        const int yb = ty * TILE + c * 8;  // first source row of the segment
+#pragma unroll
+        for(int k = 0; k < 8; k++) {
+            const int xl = k * 8 + rr;
+            const int X = tx * TILE + xl;
+            if(X < W && yb < H) {
+                uint4 v = lds[wave][xl * 8 + (c ^ k)];
+                size_t o = a.rot == 1 ? (size_t)X * H + (size_t)(H - 8 - yb) : (size_t)(W - 1 - X) * H + (size_t)yb;
+                *reinterpret_cast<uint4 *>(out + o) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic (any rectangle, any alignment): one pixel per lane.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void k_blend_generic(BlendArgs a)
+{
+    const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if(idx >= area) return;
+    const uint32_t y = idx / (uint32_t)a.w, x = idx - y * (uint32_t)a.w;
+    for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
+        uint16_t * dp = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride + x;
+        uint32_t d = *dp;
+        if(a.swap) d = px_swap16(d);
+        uint32_t fg = a.color, m = 0;
+        const size_t sp = (size_t)y * a.src_stride + x;
+        if(SRC == SRC_RGB565) {
+            uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
+            fg = a.swap ? px_swap16(v) : v;
+        }
+        else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+            uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
+            fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+            m = v >> 24;
+        }
+        else if(SRC == SRC_ARGB8565) {
+            const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
+            uint32_t v = p[0] | (p[1] << 8);
+            fg = a.swap ? px_swap16(v) : v;
+            m = p[2];
+        }
+        if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
+        const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+        uint32_t r = px_core(a, d, fg, m, idx, fnb);
+        if(a.swap) r = px_swap16(r);
+        *dp = (uint16_t)r;
+    }
+}
+
+// Scan index of the first non-black destination pixel of the area, per frame (min-reduction, atomicMin).
+__global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, long long dst_fs, int dst_stride, int w, int h,
+                                                        int n_frames, uint32_t * first_nb)
+{
+    const uint32_t area = (uint32_t)w * (uint32_t)h;
+    for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y) {
+        uint32_t best = 0xFFFFFFFFu;
+        for(uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < area; idx += gridDim.x * 256) {
+            const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
+            if(dst[(long long)f * dst_fs + (size_t)y * dst_stride + x] != 0) {
+                best = idx;  // indices only grow along this loop
+                break;
+            }
+        }
+#pragma unroll
+        for(int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
+        if((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(&first_nb[f], best);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rotate_generic(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
+                                                        int W, int H, int rot, int swap_out, int n_frames)
+{
+    const uint32_t area = (uint32_t)W * (uint32_t)H;
+    const uint32_t o = blockIdx.x * 256 + threadIdx.x;  // output index: coalesced stores
+    if(o >= area) return;
+    uint32_t x, y;
+    if(rot == 1) {  // o = x*H + (H-1-y)
+        x = o / (uint32_t)H;
+        y = (uint32_t)H - 1 - (o - x * (uint32_t)H);
+    }
+    else if(rot == 3) {  // o = (W-1-x)*H + y
+        uint32_t q = o / (uint32_t)H;
+        x = (uint32_t)W - 1 - q;
+        y = o - q * (uint32_t)H;
+    }
+    else if(rot == 2) {
+        uint32_t i = area - 1 - o;
+        y = i / (uint32_t)W;
+        x = i - y * (uint32_t)W;
+    }
+    else {
+        y = o / (uint32_t)W;
+        x = o - y * (uint32_t)W;
+    }
+    for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y) {
+        uint32_t v = in[(long long)f * in_fs + (size_t)y * W + x];
+        if(swap_out) v = px_swap16(v);
+        out[(long long)f * out_fs + o] = (uint16_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// colour conversion, split, copy, synthetic data, checksum
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t c = px_from_argb8888(in[i]);
+        out[i] = (uint16_t)(swap ? px_swap16(c) : c);
+    }
+}
+__global__ void k_to32(const uint16_t * in, uint32_t * out, size_t n, int swap)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t c = in[i];
+        out[i] = px_to32(swap ? px_swap16(c) : c);
+    }
+}
+__global__ void k_image_split(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t c, al;
+        if(fmt == SRC_ARGB8565) {
+            const uint8_t * p = reinterpret_cast<const uint8_t *>(src) + i * 3;
+            c = p[0] | (p[1] << 8);  // already in the buffer's byte order (lv_draw_sw_img.c:263)
+            al = p[2];
+        }
+        else {
+            uint32_t v = reinterpret_cast<const uint32_t *>(src)[i];
+            c = fmt == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+            if(swap) c = px_swap16(c);
+            al = v >> 24;
+        }
+        color[i] = (uint16_t)c;
+        alpha[i] = (uint8_t)al;
+    }
+}
+__global__ void k_fill16(uint16_t * buf, uint16_t color, size_t n)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) buf[i] = color;
+}
+__global__ void k_buffer_copy(uint16_t * dst, long long dst_fs, int dst_stride, const uint16_t * src, long long src_fs,
+                              int src_stride, int w, int h, int n_frames)
+{
+    const uint32_t area = (uint32_t)w * (uint32_t)h;
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if(idx >= area) return;
+    const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
+    for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y)
+        dst[(long long)f * dst_fs + (size_t)y * dst_stride + x] = src[(long long)f * src_fs + (size_t)y * src_stride + x];
+}
+
+__device__ __forceinline__ uint32_t ui_alpha(uint64_t h)
+{
+    uint32_t t = (uint32_t)(h >> 56) % 3u;
+    if(t == 0) return 0;
+    if(t == 1) return 255;
+    return 1u + ((uint32_t)(h >> 32) & 0xFFFFu) % 254u;
+}
+__global__ void k_synth(void * out, int kind, uint64_t seed, uint64_t first, size_t n)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint64_t h = fin64(seed + (first + i + 1) * 0x9E3779B97F4A7C15ULL);
+        switch(kind) {
+            case 0: reinterpret_cast<uint16_t *>(out)[i] = (uint16_t)(h & 0xFFFF); break;
+            case 1: reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)ui_alpha(h); break;
+            case 2: reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)(h & 0xFF); break;
+            case 3: reinterpret_cast<uint32_t *>(out)[i] = (uint32_t)(h & 0xFFFFFF) | (ui_alpha(h) << 24); break;
+            default: reinterpret_cast<uint32_t *>(out)[i] = (uint32_t)h; break;
+        }
+    }
+}
+__global__ void k_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, unsigned long long * sum)
+{
+    uint64_t s = 0;
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint64_t v = elem_bytes == 1   ? reinterpret_cast<const uint8_t *>(in)[i]
+                     : elem_bytes == 2 ? reinterpret_cast<const uint16_t *>(in)[i]
+                                       : reinterpret_cast<const uint32_t *>(in)[i];
+        s += fin64((first + i) * 0x9E3779B97F4A7C15ULL + v * 0xD1B54A32D192ED03ULL + 1);
+    }
+#pragma unroll
+    for(int sft = 32; sft > 0; sft >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)s, sft, 64);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(s >> 32), sft, 64);
+        s += ((uint64_t)hi << 32) | lo;
+    }
+    if((threadIdx.x & 63) == 0) atomicAdd(sum, (unsigned long long)s);
+}
+
+}  // namespace lvgpu

@@ -1,0 +1,355 @@
+// lvgpu_lvgl_shim.cpp -- LVGL-signature callbacks (include/lvgpu_lvgl.h) on top of the batched C ABI.
+//
+// Single-frame, host-buffer versions of the plug-in points of LVGL 8.x: lv_draw_sw_ctx_t.blend,
+// lv_draw_ctx_t.wait_for_finish, lv_disp_drv_t.draw_ctx_init/deinit/size and lv_disp_drv_t.flush_cb.  Each call
+// stages the touched rectangle into device memory, runs the batch kernels with n_frames = 1 and copies the
+// result back before it returns.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/lvgpu_lvgl.h"
+
+namespace {
+
+typedef void (*init_ctx_fn)(lvgpu_lv_disp_drv_t *, lvgpu_lv_draw_ctx_t *);
+typedef void (*blend_fn)(lvgpu_lv_draw_ctx_t *, const lvgpu_lv_draw_sw_blend_dsc_t *);
+typedef void (*flush_ready_fn)(lvgpu_lv_disp_drv_t *);
+
+init_ctx_fn g_sw_init_ctx = nullptr;
+blend_fn g_sw_blend_basic = nullptr;
+flush_ready_fn g_flush_ready = nullptr;
+int g_swap = 1;
+std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0};
+
+// lv_draw_sw_ctx_t (libraries/lvgl/src/draw/sw/lv_draw_sw.h:32-37) extended the way GPU back-ends extend it
+// (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.h: typedef lv_draw_sw_ctx_t lv_draw_stm32_dma2d_ctx_t).
+struct ShimCtx {
+    lvgpu_lv_draw_ctx_t base_draw;
+    blend_fn blend;
+    // --- extension ---
+    uint32_t magic;
+    lvgpu_lv_disp_drv_t * drv;
+    hipStream_t stream;
+    void * d_dst;
+    void * d_src;
+    void * d_mask;
+    size_t cap_px;
+};
+constexpr uint32_t MAGIC = 0x4C564750u;  // "LVGP"
+
+[[noreturn]] void die(const char * what, hipError_t e)
+{
+    // The callbacks return void and a silent CPU substitute would hide a broken installation.
+    fprintf(stderr, "lvgpu: %s failed: %s -- aborting (there is no CPU fallback)\n", what, hipGetErrorString(e));
+    g_errors++;
+    abort();
+}
+#define HIP_OR_DIE(expr)                     \
+    do {                                     \
+        hipError_t e_ = (expr);              \
+        if(e_ != hipSuccess) die(#expr, e_); \
+    } while(0)
+
+void * lookup(const char * name) { return dlsym(RTLD_DEFAULT, name); }
+
+void ensure_capacity(ShimCtx * s, size_t px)
+{
+    if(px <= s->cap_px) return;
+    if(s->d_dst) HIP_OR_DIE(hipFree(s->d_dst));
+    if(s->d_src) HIP_OR_DIE(hipFree(s->d_src));
+    if(s->d_mask) HIP_OR_DIE(hipFree(s->d_mask));
+    size_t cap = px < 65536 ? 65536 : px;
+    HIP_OR_DIE(hipMalloc(&s->d_dst, cap * 2));
+    HIP_OR_DIE(hipMalloc(&s->d_src, cap * 2));
+    HIP_OR_DIE(hipMalloc(&s->d_mask, cap));
+    s->cap_px = cap;
+}
+
+inline int aw(const lvgpu_lv_area_t * a) { return a->x2 - a->x1 + 1; }
+inline int ah(const lvgpu_lv_area_t * a) { return a->y2 - a->y1 + 1; }
+
+void flush_ready(lvgpu_lv_disp_drv_t * drv)
+{
+    if(g_flush_ready == nullptr) g_flush_ready = (flush_ready_fn)lookup("lv_disp_flush_ready");
+    if(g_flush_ready) g_flush_ready(drv);
+    else if(drv->draw_buf) {  // libraries/lvgl/src/hal/lv_hal_disp.c:519-522
+        drv->draw_buf->flushing = 0;
+        drv->draw_buf->flushing_last = 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void lvgpu_lvgl_bind(void * init_ctx, void * blend_basic, void * flush_ready_p)
+{
+    g_sw_init_ctx = (init_ctx_fn)init_ctx;
+    g_sw_blend_basic = (blend_fn)blend_basic;
+    g_flush_ready = (flush_ready_fn)flush_ready_p;
+}
+
+void lvgpu_lvgl_set_color_16_swap(int swap) { g_swap = swap ? 1 : 0; }
+
+size_t lvgpu_draw_ctx_size(void) { return sizeof(ShimCtx); }
+
+void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_ctx)
+{
+    if(g_sw_init_ctx == nullptr) g_sw_init_ctx = (init_ctx_fn)lookup("lv_draw_sw_init_ctx");
+    if(g_sw_blend_basic == nullptr) g_sw_blend_basic = (blend_fn)lookup("lv_draw_sw_blend_basic");
+    ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
+    if(g_sw_init_ctx == nullptr) {
+        fprintf(stderr, "lvgpu: lv_draw_sw_init_ctx not bound (call lvgpu_lvgl_bind) -- aborting\n");
+        abort();
+    }
+    g_sw_init_ctx(drv, draw_ctx);  // fills the primitive table and zeroes lv_draw_sw_ctx_t (lv_draw_sw.c:40-65)
+    memset(reinterpret_cast<char *>(s) + sizeof(lvgpu_lv_draw_ctx_t) + sizeof(blend_fn), 0,
+           sizeof(ShimCtx) - sizeof(lvgpu_lv_draw_ctx_t) - sizeof(blend_fn));
+    s->magic = MAGIC;
+    s->drv = drv;
+    s->blend = lvgpu_blend;
+    s->base_draw.wait_for_finish = lvgpu_wait_for_finish;
+    int dev = -1;
+    HIP_OR_DIE(hipGetDevice(&dev));  // the calling thread's current device; fails when there is none
+    HIP_OR_DIE(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+}
+
+void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_ctx)
+{
+    (void)drv;
+    ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
+    if(s->magic == MAGIC) {
+        if(s->stream) (void)hipStreamSynchronize(s->stream);
+        if(s->d_dst) (void)hipFree(s->d_dst);
+        if(s->d_src) (void)hipFree(s->d_src);
+        if(s->d_mask) (void)hipFree(s->d_mask);
+        if(s->stream) (void)hipStreamDestroy(s->stream);
+    }
+    memset(s, 0, sizeof(ShimCtx));  // lv_draw_sw_deinit_ctx zeroes the context too (lv_draw_sw.c:67-73)
+}
+
+void lvgpu_wait_for_finish(lvgpu_lv_draw_ctx_t * draw_ctx)
+{
+    ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
+    if(s->magic == MAGIC && s->stream) HIP_OR_DIE(hipStreamSynchronize(s->stream));
+}
+
+void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_dsc_t * dsc)
+{
+    ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
+    lvgpu_lv_disp_drv_t * drv = s->drv;
+
+    // Requests outside this library's coverage go to the host's own lv_draw_sw_blend_basic, the convention of
+    // every LVGL GPU back-end (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130,207): a custom
+    // set_px_cb, and the ARGB8565 destination layout of a transparent screen.
+    if(drv->set_px_cb != nullptr || drv->screen_transp) {
+        g_blend_delegated++;
+        if(g_sw_blend_basic) g_sw_blend_basic(draw_ctx, dsc);
+        else {
+            fprintf(stderr, "lvgpu: request needs lv_draw_sw_blend_basic, which is not bound -- aborting\n");
+            abort();
+        }
+        return;
+    }
+
+    // lv_draw_sw_blend_basic, libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:111-166
+    uint8_t * mask;
+    if(dsc->mask_buf && dsc->mask_res == LVGPU_MASK_RES_TRANSP) return;
+    else if(dsc->mask_res == LVGPU_MASK_RES_FULL_COVER) mask = nullptr;
+    else mask = dsc->mask_buf;
+
+    const int dest_stride = aw(draw_ctx->buf_area);
+    lvgpu_lv_area_t a;
+    a.x1 = dsc->blend_area->x1 > draw_ctx->clip_area->x1 ? dsc->blend_area->x1 : draw_ctx->clip_area->x1;
+    a.y1 = dsc->blend_area->y1 > draw_ctx->clip_area->y1 ? dsc->blend_area->y1 : draw_ctx->clip_area->y1;
+    a.x2 = dsc->blend_area->x2 < draw_ctx->clip_area->x2 ? dsc->blend_area->x2 : draw_ctx->clip_area->x2;
+    a.y2 = dsc->blend_area->y2 < draw_ctx->clip_area->y2 ? dsc->blend_area->y2 : draw_ctx->clip_area->y2;
+    if(a.x1 > a.x2 || a.y1 > a.y2) return;
+    const int w = aw(&a), h = ah(&a);
+
+    uint16_t * dest = reinterpret_cast<uint16_t *>(draw_ctx->buf) +
+                      (size_t)dest_stride * (a.y1 - draw_ctx->buf_area->y1) + (a.x1 - draw_ctx->buf_area->x1);
+    const uint16_t * src = dsc->src_buf;
+    int src_stride = 0;
+    if(src) {
+        src_stride = aw(dsc->blend_area);
+        src += (size_t)src_stride * (a.y1 - dsc->blend_area->y1) + (a.x1 - dsc->blend_area->x1);
+    }
+    int mask_stride = 0;
+    if(mask) {
+        if(drv->antialiasing == 0) {  // :150-156, in place over the whole mask as the reference does
+            const int32_t n = aw(dsc->mask_area) * ah(dsc->mask_area);
+            for(int32_t i = 0; i < n; i++) mask[i] = mask[i] > 128 ? 255 : 0;
+        }
+        mask_stride = aw(dsc->mask_area);
+        mask += (size_t)mask_stride * (a.y1 - dsc->mask_area->y1) + (a.x1 - dsc->mask_area->x1);
+    }
+
+    const size_t px = (size_t)w * h;
+    ensure_capacity(s, px);
+    hipStream_t st = s->stream;
+    const bool dst_needed = !(src == nullptr && mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0) &&
+                            !(src != nullptr && mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0);
+    if(dst_needed)
+        HIP_OR_DIE(hipMemcpy2DAsync(s->d_dst, (size_t)w * 2, dest, (size_t)dest_stride * 2, (size_t)w * 2, h,
+                                    hipMemcpyHostToDevice, st));
+    if(src)
+        HIP_OR_DIE(hipMemcpy2DAsync(s->d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h,
+                                    hipMemcpyHostToDevice, st));
+    if(mask)
+        HIP_OR_DIE(hipMemcpy2DAsync(s->d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, h, hipMemcpyHostToDevice, st));
+
+    lvgpu_blend_batch_t b;
+    memset(&b, 0, sizeof(b));
+    b.dst = s->d_dst;
+    b.dst_frame_stride = (int64_t)px;
+    b.buf_area = lvgpu_area_t{0, 0, (int16_t)(w - 1), (int16_t)(h - 1)};
+    b.clip_area = b.buf_area;
+    b.blend_area = b.buf_area;
+    b.mask_area = b.buf_area;
+    b.src = src ? s->d_src : nullptr;
+    b.src_format = src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
+    b.mask = mask ? reinterpret_cast<const uint8_t *>(s->d_mask) : nullptr;
+    b.mask_res = LVGPU_MASK_RES_CHANGED;
+    b.n_frames = 1;
+    b.color = dsc->color;
+    b.opa = dsc->opa;
+    b.blend_mode = dsc->blend_mode;
+    b.color_16_swap = (uint8_t)g_swap;
+    int rc = lvgpu_blend_batch(&b, st);
+    if(rc != LVGPU_OK) {
+        fprintf(stderr, "lvgpu: lvgpu_blend_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+        g_errors++;
+        abort();
+    }
+    HIP_OR_DIE(hipMemcpy2DAsync(dest, (size_t)dest_stride * 2, s->d_dst, (size_t)w * 2, (size_t)w * 2, h,
+                                hipMemcpyDeviceToHost, st));
+    // src_buf / mask_buf may be reused by the caller as soon as we return, and the CPU reads the draw buffer.
+    HIP_OR_DIE(hipStreamSynchronize(st));
+    g_blend_gpu++;
+}
+
+void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvgpu_lv_color_t * color_p)
+{
+    const lvgpu_flush_cfg_t * cfg = reinterpret_cast<const lvgpu_flush_cfg_t *>(drv->user_data);
+    if(cfg == nullptr || cfg->draw_bitmap == nullptr) {
+        fprintf(stderr, "lvgpu_flush_cb: drv->user_data must point to a lvgpu_flush_cfg_t with a draw_bitmap sink\n");
+        abort();
+    }
+    const int x_start = area->x1, x_end = area->x2, y_start = area->y1, y_end = area->y2;
+    const int W = x_end - x_start + 1, H = y_end - y_start + 1;
+    const int rot = cfg->sw_rotate;
+
+    if(cfg->trans_size == 0) {  // src/lv_port.c:568-570
+        cfg->draw_bitmap(cfg->user, x_start, y_start, x_end + 1, y_end + 1, color_p);
+        flush_ready(drv);
+        return;
+    }
+    const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
+    const int step = transposing ? (int)(cfg->trans_size / (uint32_t)H) : (int)(cfg->trans_size / (uint32_t)W);
+    if(step <= 0) {
+        fprintf(stderr, "lvgpu_flush_cb: trans_size %u is smaller than one line of the flushed area\n", cfg->trans_size);
+        abort();
+    }
+
+    // rotate the whole area on the device
+    const size_t px = (size_t)W * H;
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_OR_DIE(hipMalloc(&d_in, px * 2));
+    HIP_OR_DIE(hipMalloc(&d_out, px * 2));
+    uint16_t * panel = static_cast<uint16_t *>(malloc(px * 2));
+    HIP_OR_DIE(hipMemcpy(d_in, color_p, px * 2, hipMemcpyHostToDevice));
+    lvgpu_flush_batch_t f;
+    memset(&f, 0, sizeof(f));
+    f.in = d_in;
+    f.out = d_out;
+    f.in_frame_stride = f.out_frame_stride = (int64_t)px;
+    f.width = W;
+    f.height = H;
+    f.rotation = rot;
+    f.swap_bytes = cfg->swap_bytes;
+    f.n_frames = 1;
+    int rc = lvgpu_flush_rotate_batch(&f, nullptr);
+    if(rc != LVGPU_OK) {
+        fprintf(stderr, "lvgpu: lvgpu_flush_rotate_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+        abort();
+    }
+    HIP_OR_DIE(hipMemcpy(panel, d_out, px * 2, hipMemcpyDeviceToHost));
+    HIP_OR_DIE(hipFree(d_in));
+    HIP_OR_DIE(hipFree(d_out));
+
+    // Hand the panel image to the sink in the reference's transport chunks (src/lv_port.c:466-566): same
+    // rectangles, same order.  Each chunk is a contiguous slice of the rotated image.
+    const int span = transposing ? W : H;          // chunks advance along x (rotated) or y
+    const int line = transposing ? H : W;          // pixels per advanced line in the panel image
+    const int max_step = step > span ? span : step;
+    bool first = true;
+    for(int done = 0; done < span; done += max_step) {
+        const int n = span - done > max_step ? max_step : span - done;
+        int xd0, yd0, xd1, yd1;
+        switch(rot) {
+            case LVGPU_ROT_90: {  // columns from the left edge (:482-484, :506-509)
+                const int xs = x_start + done, xe = xs + n - 1;
+                xd0 = drv->ver_res - y_end - 1;
+                xd1 = drv->ver_res - y_start - 1;
+                yd0 = xs;
+                yd1 = xe;
+                break;
+            }
+            case LVGPU_ROT_270: {  // columns from the right edge (:485-487, :517-520)
+                const int xe = x_end - done, xs = xe - n + 1;
+                xd0 = y_start;
+                xd1 = y_end;
+                yd0 = drv->hor_res - xe - 1;
+                yd1 = drv->hor_res - xs - 1;
+                break;
+            }
+            case LVGPU_ROT_180: {  // rows from the bottom edge (:491-494, :528-531)
+                const int ye = y_end - done, ys = ye - n + 1;
+                xd0 = drv->hor_res - x_end - 1;
+                xd1 = drv->hor_res - x_start - 1;
+                yd0 = drv->ver_res - ye - 1;
+                yd1 = drv->ver_res - ys - 1;
+                break;
+            }
+            default: {  // rows from the top edge (:488-490, :539-542)
+                const int ys = y_start + done, ye = ys + n - 1;
+                xd0 = x_start;
+                xd1 = x_end;
+                yd0 = ys;
+                yd1 = ye;
+                break;
+            }
+        }
+        if(first) {
+            if(cfg->draw_wait) cfg->draw_wait(cfg->user);  // :548-551
+            first = false;
+        }
+        cfg->draw_bitmap(cfg->user, xd0, yd0, xd1 + 1, yd1 + 1, panel + (size_t)done * line);
+    }
+    free(panel);
+    g_flush_gpu++;
+    flush_ready(drv);  // :571
+}
+
+void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out)
+{
+    out->blend_gpu = g_blend_gpu;
+    out->blend_delegated = g_blend_delegated;
+    out->flush_gpu = g_flush_gpu;
+    out->errors = g_errors;
+}
+void lvgpu_lvgl_reset_stats(void)
+{
+    g_blend_gpu = 0;
+    g_blend_delegated = 0;
+    g_flush_gpu = 0;
+    g_errors = 0;
+}
+
+}  // extern "C"
