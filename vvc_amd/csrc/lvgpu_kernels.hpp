@@ -38,6 +38,16 @@ struct BlendArgs {
     int swap_out;          // byte-swap pixels written to out
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2).  Remap the block id
+// so that the blocks of one XCD walk one contiguous eighth of the batch: neighbouring tiles (which share 128-byte
+// lines at their edges) and neighbouring chunks then meet in the same L2.  Bijective for any grid size; affects
+// speed only, never results.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_blocks)
+{
+    const uint32_t q = n_blocks >> 3, r = n_blocks & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // one pixel
 // ---------------------------------------------------------------------------------------------------------------
@@ -157,14 +167,15 @@ __device__ __forceinline__ uint4 reverse_group(uint4 v)
 // Block b handles chunk (b % cpf) of frame (b / cpf): LIN_UNROLL groups per lane, loads first, then math, stores.
 // out (optional): rot NONE -> same order; rot 180 -> whole-frame reversal (src/lv_port.c:522-527, :533-538).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int LIN_UNROLL = 4;
+constexpr int LIN_UNROLL = 2;
 constexpr int LIN_CHUNK = 256 * LIN_UNROLL;  // groups per block
 
 template <int SRC>
 __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf, uint32_t cpf)
 {
-    const uint32_t f = blockIdx.x / cpf;
-    const uint32_t c = blockIdx.x - f * cpf;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t f = blk / cpf;
+    const uint32_t c = blk - f * cpf;
     uint16_t * dst = a.dst + (long long)f * a.dst_fs;
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
     __shared__ uint4 lds[4][512];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t wt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
     const bool live = wt < n_tiles;
     const uint32_t f = live ? wt / tpf : 0;
     const uint32_t t = live ? wt - f * tpf : 0;
