@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from vvc_amd import lvgpu  # noqa: E402
+from vvc_amd import lvgpu, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 SEED_DST, SEED_SRC, SEED_MASK = 0x5EED0001, 0x5EED0002, 0x5EED0003
@@ -86,22 +86,16 @@ def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    rank, world, local_rank, dist = sharding.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    torch.cuda.set_device(local_rank)
     dev = torch.cuda.current_device()
     lvgpu.init(dev)
 
     W, H, n = args.width, args.height, args.frames_per_gpu
     px = W * H
-    first = rank * n * px  # global element index of this shard: inputs depend only on the global frame index
+    lo, hi = sharding.frame_range(rank, world, n * world)  # this rank's global frame indices
+    assert hi - lo == n
+    first = lo * px  # global element index of this shard: inputs depend only on the global frame index
     kind = lvgpu.SYNTH_ARGB_UI if args.mask == "ui" else lvgpu.SYNTH_ARGB_UNI
     dst = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
     src = lvgpu.synth(kind, SEED_SRC, first, (n, H, W))
@@ -131,9 +125,7 @@ def main():
         step()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.barrier(dist)
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
@@ -145,10 +137,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        t = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, ev_ms = float(t[0]), float(t[1])
+    dt, ev_ms = sharding.max_over_ranks(dist, [dt, ev_ms])
 
     if rank == 0:
         total_px = px * n * world * args.steps

@@ -122,7 +122,10 @@ typedef struct {
     uint8_t opa;              /* dsc->opa                                                                        */
     uint8_t blend_mode;       /* dsc->blend_mode (LVGPU_BLEND_*)                                                 */
     uint8_t color_16_swap;    /* LV_COLOR_16_SWAP of the buffers                                                 */
-    uint8_t reserved[2];
+    uint8_t dst_argb8565;     /* 1: dst is the 3-byte ARGB8565 layout {c.lo, c.hi, A} that lv_draw_sw_blend_basic draws   */
+                              /* into when disp->driver->screen_transp is set (lv_draw_sw_blend.c:129-133, 177-184):    */
+                              /* fill_argb / map_argb semantics; dst_frame_stride stays in pixels (3 bytes each)       */
+    uint8_t reserved;
 } lvgpu_blend_batch_t;
 
 int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
@@ -205,7 +208,8 @@ enum {
     LVGPU_SYNTH_ARGB_UNI = 4  /* u32: uniform                                                                    */
 };
 /* Element i (global index first_index + i) is a pure function of (kind, seed, global index): counter-based
- * splitmix64, identical to the CPU oracle's generator, so shards are reproducible for any frame partition. */
+ * splitmix64 (out[i] = f(seed + (first_index+i+1) * 0x9E3779B97F4A7C15)), so shards are reproducible for any frame
+ * partition. */
 int lvgpu_synth(void * dev_out, int kind, uint64_t seed, uint64_t first_index, size_t count, void * stream);
 /* Order-independent 64-bit checksum of n 16-bit (elem_bytes=2), 8-bit (1) or 32-bit (4) elements:
  * sum over i of splitmix64(first_index + i, value_i) mod 2^64.  *dev_sum64 is ADDED to (zero it first). */

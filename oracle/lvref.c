@@ -292,6 +292,14 @@ static uint16_t blend_mode_px(int mode, uint16_t fg, uint16_t bg, uint8_t opa, i
         r = (unsigned)((fr * br) >> 5);
         b = (unsigned)((fb * bb) >> 5);
         g = (unsigned)((fgn * bgn) >> 6);
+        if(swap) {
+            /* :1040 goes through LV_COLOR_SET_G16 of the swapped build (lv_color.h:134), a macro that evaluates its
+             * value argument twice: green_h is stored first, and the second evaluation, which yields green_l, then
+             * reads the foreground's green with the NEW high bits and the old low bits. */
+            unsigned gh = (g >> 3) & 7u;
+            unsigned g2 = (((gh << 3) + ((unsigned)fgn & 7u)) * (unsigned)bgn) >> 6;
+            g = (gh << 3) | (g2 & 7u);
+        }
     }
     uint16_t c = from_rgb(r, g, b, swap);
     if(opa == OPA_COVER) return c;

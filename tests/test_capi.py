@@ -1,0 +1,182 @@
+"""CPU: the C-ABI library loads, exports every function its headers declare, and its PODs have the layout the
+headers (and LVGL's own types) say.  No compute calls here."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+INC = os.path.join(ROOT, "include")
+
+
+def test_library_exports_every_declared_symbol():
+    from vvc_amd import _lib
+    L = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "liblvgpu.so does not export %s" % n
+    assert L.lvgpu_version() == 0x000100
+
+
+def test_argument_errors_need_no_gpu():
+    from vvc_amd import _lib
+    L = _lib.lib()
+    assert L.lvgpu_blend_batch(None, None) == -1
+    assert b"NULL" in L.lvgpu_last_error()
+    assert L.lvgpu_flush_rotate_batch(None, None) == -1
+    f = _lib.FlushBatch()
+    f.width, f.height, f.rotation, f.n_frames = 8, 8, 7, 1
+    assert L.lvgpu_flush_rotate_batch(C.byref(f), None) == -1
+    b = _lib.BlendBatch()
+    b.n_frames = -1
+    assert L.lvgpu_blend_batch(C.byref(b), None) == -1
+    b.n_frames = 0
+    assert L.lvgpu_blend_batch(C.byref(b), None) == 0        # empty batch is a no-op
+    assert L.lvgpu_color_fill(None, 0, 0, None) == 0
+    assert L.lvgpu_color_fill(None, 0, 4, None) == -1
+
+
+PROBE = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "lvgpu.h"
+#include "lvgpu_lvgl.h"
+#define P(name, v) printf("\"%s\": %ld,\n", name, (long)(v))
+int main(void) {
+    printf("{\n");
+    P("sizeof(lvgpu_area_t)", sizeof(lvgpu_area_t));
+    P("sizeof(lvgpu_blend_batch_t)", sizeof(lvgpu_blend_batch_t));
+    P("blend.dst", offsetof(lvgpu_blend_batch_t, dst));
+    P("blend.buf_area", offsetof(lvgpu_blend_batch_t, buf_area));
+    P("blend.src", offsetof(lvgpu_blend_batch_t, src));
+    P("blend.mask", offsetof(lvgpu_blend_batch_t, mask));
+    P("blend.mask_area", offsetof(lvgpu_blend_batch_t, mask_area));
+    P("blend.n_frames", offsetof(lvgpu_blend_batch_t, n_frames));
+    P("blend.color", offsetof(lvgpu_blend_batch_t, color));
+    P("blend.color_16_swap", offsetof(lvgpu_blend_batch_t, color_16_swap));
+    P("sizeof(lvgpu_flush_batch_t)", sizeof(lvgpu_flush_batch_t));
+    P("flush.out", offsetof(lvgpu_flush_batch_t, out));
+    P("flush.width", offsetof(lvgpu_flush_batch_t, width));
+    P("flush.n_frames", offsetof(lvgpu_flush_batch_t, n_frames));
+    P("sizeof(lvgpu_blend_flush_batch_t)", sizeof(lvgpu_blend_flush_batch_t));
+    P("bf.out", offsetof(lvgpu_blend_flush_batch_t, out));
+    P("bf.rotation", offsetof(lvgpu_blend_flush_batch_t, rotation));
+    /* mirrors of the LVGL types */
+    P("sizeof(lv_area_t)", sizeof(lvgpu_lv_area_t));
+    P("sizeof(lv_color_t)", sizeof(lvgpu_lv_color_t));
+    P("sizeof(lv_draw_sw_blend_dsc_t)", sizeof(lvgpu_lv_draw_sw_blend_dsc_t));
+    P("blend_dsc.blend_area", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, blend_area));
+    P("blend_dsc.src_buf", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, src_buf));
+    P("blend_dsc.color", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, color));
+    P("blend_dsc.mask_buf", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, mask_buf));
+    P("blend_dsc.mask_res", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, mask_res));
+    P("blend_dsc.mask_area", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, mask_area));
+    P("blend_dsc.opa", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, opa));
+    P("blend_dsc.blend_mode", offsetof(lvgpu_lv_draw_sw_blend_dsc_t, blend_mode));
+    P("sizeof(lv_draw_ctx_t)", sizeof(lvgpu_lv_draw_ctx_t));
+    P("draw_ctx.buf", offsetof(lvgpu_lv_draw_ctx_t, buf));
+    P("draw_ctx.buf_area", offsetof(lvgpu_lv_draw_ctx_t, buf_area));
+    P("draw_ctx.clip_area", offsetof(lvgpu_lv_draw_ctx_t, clip_area));
+    P("draw_ctx.init_buf", offsetof(lvgpu_lv_draw_ctx_t, init_buf));
+    P("draw_ctx.wait_for_finish", offsetof(lvgpu_lv_draw_ctx_t, wait_for_finish));
+    P("draw_ctx.buffer_copy", offsetof(lvgpu_lv_draw_ctx_t, buffer_copy));
+    P("draw_ctx.layer_instance_size", offsetof(lvgpu_lv_draw_ctx_t, layer_instance_size));
+    P("draw_ctx.user_data", offsetof(lvgpu_lv_draw_ctx_t, user_data));
+    P("sizeof(lv_disp_draw_buf_t)", sizeof(lvgpu_lv_disp_draw_buf_t));
+    P("draw_buf.buf1", offsetof(lvgpu_lv_disp_draw_buf_t, buf1));
+    P("draw_buf.buf_act", offsetof(lvgpu_lv_disp_draw_buf_t, buf_act));
+    P("draw_buf.size", offsetof(lvgpu_lv_disp_draw_buf_t, size));
+    P("draw_buf.flushing", offsetof(lvgpu_lv_disp_draw_buf_t, flushing));
+    P("draw_buf.flushing_last", offsetof(lvgpu_lv_disp_draw_buf_t, flushing_last));
+    P("sizeof(lv_disp_drv_t)", sizeof(lvgpu_lv_disp_drv_t));
+    P("disp_drv.hor_res", offsetof(lvgpu_lv_disp_drv_t, hor_res));
+    P("disp_drv.ver_res", offsetof(lvgpu_lv_disp_drv_t, ver_res));
+    P("disp_drv.draw_buf", offsetof(lvgpu_lv_disp_drv_t, draw_buf));
+    P("disp_drv.flush_cb", offsetof(lvgpu_lv_disp_drv_t, flush_cb));
+    P("disp_drv.set_px_cb", offsetof(lvgpu_lv_disp_drv_t, set_px_cb));
+    P("disp_drv.draw_ctx", offsetof(lvgpu_lv_disp_drv_t, draw_ctx));
+    P("disp_drv.draw_ctx_init", offsetof(lvgpu_lv_disp_drv_t, draw_ctx_init));
+    P("disp_drv.draw_ctx_deinit", offsetof(lvgpu_lv_disp_drv_t, draw_ctx_deinit));
+    P("disp_drv.draw_ctx_size", offsetof(lvgpu_lv_disp_drv_t, draw_ctx_size));
+    P("disp_drv.user_data", offsetof(lvgpu_lv_disp_drv_t, user_data));
+    /* bitfield word: set each field in a zeroed struct and print the word at offset 24 */
+    {
+        const char *names[] = {"direct_mode", "full_refresh", "sw_rotate", "antialiasing", "rotated", "screen_transp"};
+        for(int i = 0; i < 6; i++) {
+            lvgpu_lv_disp_drv_t d; unsigned w;
+            __builtin_memset(&d, 0, sizeof d);
+            if(i == 0) d.direct_mode = 1; if(i == 1) d.full_refresh = 1; if(i == 2) d.sw_rotate = 1;
+            if(i == 3) d.antialiasing = 1; if(i == 4) d.rotated = 3; if(i == 5) d.screen_transp = 1;
+            __builtin_memcpy(&w, (char *)&d + 24, 4);
+            printf("\"bits.%s\": %u,\n", names[i], w);
+        }
+    }
+    P("LVGPU_MASK_RES_CHANGED", LVGPU_MASK_RES_CHANGED);
+    printf("\"end\": 0}\n");
+    return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def probe():
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "probe.c")
+        open(src, "w").write(PROBE)
+        exe = os.path.join(td, "probe")
+        subprocess.check_call(["gcc", "-std=gnu11", "-Wall", "-I", INC, src, "-o", exe])
+        return json.loads(subprocess.check_output([exe]).decode())
+
+
+def test_pod_layout_matches_ctypes(probe):
+    from vvc_amd import _lib
+    assert probe["sizeof(lvgpu_area_t)"] == C.sizeof(_lib.Area) == 8
+    assert probe["sizeof(lvgpu_blend_batch_t)"] == C.sizeof(_lib.BlendBatch)
+    for f in ("dst", "buf_area", "src", "mask", "mask_area", "n_frames", "color", "color_16_swap"):
+        assert probe["blend." + f] == getattr(_lib.BlendBatch, f).offset, f
+    assert probe["sizeof(lvgpu_flush_batch_t)"] == C.sizeof(_lib.FlushBatch)
+    assert probe["flush.out"] == _lib.FlushBatch.out.offset
+    assert probe["flush.width"] == _lib.FlushBatch.width.offset
+    assert probe["flush.n_frames"] == _lib.FlushBatch.n_frames.offset
+    assert probe["sizeof(lvgpu_blend_flush_batch_t)"] == C.sizeof(_lib.BlendFlushBatch)
+    assert probe["bf.out"] == _lib.BlendFlushBatch.out.offset
+    assert probe["bf.rotation"] == _lib.BlendFlushBatch.rotation.offset
+
+
+def test_lvgl_mirror_layout_matches_real_lvgl(probe):
+    """The mirror structs of include/lvgpu_lvgl.h against offsetof/sizeof taken from the real LVGL headers
+    (recorded in tests/golden/golden.json by oracle/gen_golden.py)."""
+    meta = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    for swap in ("0", "1"):
+        lay = meta["swap"][swap]["layout"]
+        for k, v in lay.items():
+            if k in probe:
+                assert probe[k] == v, (k, probe[k], v)
+        for k, v in meta["swap"][swap]["disp_drv_bits"].items():
+            assert probe["bits." + k] == v, k
+        assert lay["LV_DRAW_MASK_RES_CHANGED"] == probe["LVGPU_MASK_RES_CHANGED"] == 2
+        assert (lay["LV_BLEND_MODE_NORMAL"], lay["LV_BLEND_MODE_ADDITIVE"], lay["LV_BLEND_MODE_SUBTRACTIVE"],
+                lay["LV_BLEND_MODE_MULTIPLY"]) == (0, 1, 2, 3)
+        assert (lay["LV_DISP_ROT_90"], lay["LV_DISP_ROT_180"], lay["LV_DISP_ROT_270"]) == (1, 2, 3)
+        assert lay["LV_IMG_CF_TRUE_COLOR_ALPHA"] == 5
+
+
+def test_draw_ctx_size_covers_lv_draw_sw_ctx():
+    from vvc_amd import _lib
+    meta = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    assert _lib.lib().lvgpu_draw_ctx_size() >= meta["swap"]["1"]["layout"]["sizeof(lv_draw_sw_ctx_t)"]
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under vvc_amd/ may mention it."""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "vvc_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                assert "lvref" not in text and "oracle" not in text.lower().replace("oracle/_ref", ""), os.path.join(dp, f)

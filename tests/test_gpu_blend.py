@@ -152,3 +152,63 @@ def test_blend_noop_and_errors(gpu):
         gpu.lv_draw_sw_blend(ctx, gpu.BlendDsc((0, 0, 7, 7), src_buf=d, src_format=9))
     e = torch.zeros((0, 8, 8), dtype=torch.int16, device="cuda")                     # empty batch
     gpu.lv_draw_sw_blend(gpu.DrawCtx(e), gpu.BlendDsc((0, 0, 7, 7), color=1))
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_blend_modes(gpu, oracle, swap, mode):
+    """Additive / subtractive / multiply (fill_blended, map_blended) incl. the swapped build's green quirks;
+    mode 4 (REPLACE) is 'unsupported' in the reference: a warning and no drawing."""
+    rng = np.random.default_rng(900 + mode + 10 * swap)
+    N = 2
+    for (W, H, ba, clip) in [(96, 40, (0, 0, 95, 39), (0, 0, 95, 39)), (67, 19, (-2, 3, 60, 17), (1, 1, 64, 15))]:
+        area = (0, 0, W - 1, H - 1)
+        bw, bh = ba[2] - ba[0] + 1, ba[3] - ba[1] + 1
+        for opa in (2, 3, 128, 252, 253, 255):
+            for has_src in (0, 1):
+                for has_mask in (0, 1):
+                    dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+                    src = rng.integers(0, 65536, (N, bh, bw), dtype=np.uint16) if has_src else None
+                    mask = rand_mask(rng, (N, bh, bw)) if has_mask else None
+                    color = int(rng.integers(0, 65536))
+                    exp = _oracle_frames(oracle, dst, area, clip, ba, src, color, mask, 2, ba, opa, mode, swap)
+                    d = to_dev(dst)
+                    ctx = gpu.DrawCtx(d, area, clip, color_16_swap=swap)
+                    dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color,
+                                       mask_buf=None if mask is None else to_dev(mask), opa=opa, blend_mode=mode)
+                    gpu.lv_draw_sw_blend(ctx, dsc)
+                    assert np.array_equal(to_np(d, np.uint16), exp), (W, opa, has_src, has_mask)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_blend_argb8565_destination(gpu, oracle, swap):
+    """screen_transp: 3-byte destination pixels, fill_argb / map_argb / lv_color_mix_with_alpha, incl. the
+    mask-row quirk of fill_argb's opaque branch and the blend modes through set_px_argb_blend."""
+    rng = np.random.default_rng(321 + swap)
+    N = 2
+    W, H = 41, 13
+    area = (0, 0, W - 1, H - 1)
+    for t in range(250):
+        dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+        dst[..., 2] = rand_mask(rng, (N, H, W))
+        x1, y1 = int(rng.integers(-2, W - 2)), int(rng.integers(-2, H - 1))
+        x2, y2 = int(rng.integers(x1, W + 2)), int(rng.integers(y1, H + 2))
+        ba = (x1, y1, x2, y2)
+        cx1, cy1 = int(rng.integers(0, W)), int(rng.integers(0, H))
+        clip = (cx1, cy1, int(rng.integers(cx1, W)), int(rng.integers(cy1, H)))
+        bw, bh = x2 - x1 + 1, y2 - y1 + 1
+        src = rng.integers(0, 65536, (N, bh, bw), dtype=np.uint16) if rng.random() < 0.5 else None
+        mask = rand_mask(rng, (N, bh, bw)) if rng.random() < 0.6 else None
+        opa = int(rng.choice(OPAS))
+        mode = int(rng.choice([0, 0, 1, 2, 3, 4]))
+        color = int(rng.integers(0, 65536))
+        exp = dst.copy()
+        for f in range(N):
+            oracle.blend(exp[f], area, clip, ba, src=None if src is None else src[f], color=color,
+                         mask=None if mask is None else mask[f], opa=opa, blend_mode=mode, swap=swap, screen_transp=1)
+        d = to_dev(dst)
+        ctx = gpu.DrawCtx(d, area, clip, color_16_swap=swap, screen_transp=1)
+        dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), opa=opa, blend_mode=mode)
+        gpu.lv_draw_sw_blend(ctx, dsc)
+        assert np.array_equal(to_np(d, np.uint8), exp), (t, opa, mode, src is not None, mask is not None)

@@ -41,7 +41,7 @@ class BlendBatch(C.Structure):
         ("mask", C.c_void_p), ("mask_frame_stride", C.c_int64), ("mask_area", Area),
         ("n_frames", C.c_int32), ("src_format", C.c_int32),
         ("color", C.c_uint16), ("mask_res", C.c_uint8), ("opa", C.c_uint8),
-        ("blend_mode", C.c_uint8), ("color_16_swap", C.c_uint8), ("reserved", C.c_uint8 * 2),
+        ("blend_mode", C.c_uint8), ("color_16_swap", C.c_uint8), ("dst_argb8565", C.c_uint8), ("reserved", C.c_uint8),
     ]
 
 

@@ -126,6 +126,14 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
         a.mask = mask + (size_t)a.mask_stride * (area.y1 - d->mask_area.y1) + (area.x1 - d->mask_area.x1);   // :159
     }
     a.color = a.swap ? bswap16(d->color) : d->color;
+    a.raw_opa = d->opa;
+    a.raw_mode = d->blend_mode;
+    a.has_mask = masked ? 1 : 0;
+    if(d->dst_argb8565) {  // :177-184: fill_argb / map_argb whatever the blend mode
+        a.dst = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d->dst) +
+                ((size_t)a.dst_stride * (area.y1 - d->buf_area.y1) + (area.x1 - d->buf_area.x1)) * 3);   // :129-133
+        return R_WORK;
+    }
 
     const bool fill = d->src_format == LVGPU_SRC_FILL;
     if(d->blend_mode == LVGPU_BLEND_NORMAL) {                                 // :186-193
@@ -219,6 +227,17 @@ struct LaunchTile {
     }
 };
 template <int SRC>
+struct LaunchArgbDst {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+        dim3 grid((area + 255) / 256, std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_blend_argb_dst<SRC>, grid, dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+template <int SRC>
 struct LaunchGeneric {
     static int run(const BlendArgs & a, hipStream_t st)
     {
@@ -254,8 +273,12 @@ bool tile_ok(const BlendArgs & a, int fmt)
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
 
-int launch_blend(BlendArgs & a, int fmt, hipStream_t st)
+int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
 {
+    if(argb_dst) {
+        g_last_kernel = "k_blend_argb_dst";
+        return dispatch_src<LaunchArgbDst>(fmt, a, st);
+    }
     uint32_t * scratch = nullptr;
     int rc = prepare_first_nb(a, st, &scratch);
     if(rc != LVGPU_OK) return rc;
@@ -378,7 +401,7 @@ int lvgpu_blend_batch(const lvgpu_blend_batch_t * d, void * stream)
     g_last_kernel = "";
     int r = resolve_blend(d, a, area);
     if(r <= 0) return r;
-    return launch_blend(a, d->src_format, (hipStream_t)stream);
+    return launch_blend(a, d->src_format, (hipStream_t)stream, d->dst_argb8565 != 0);
 }
 
 int lvgpu_flush_rotate_batch(const lvgpu_flush_batch_t * d, void * stream)
@@ -400,6 +423,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
     if(d->out == nullptr) return fail(LVGPU_ERR_ARG, "out is NULL");
     if(d->rotation < LVGPU_ROT_NONE || d->rotation > LVGPU_ROT_270) return fail(LVGPU_ERR_ARG, "bad rotation %d", d->rotation);
+    if(d->blend.dst_argb8565) return fail(LVGPU_ERR_UNSUPPORTED, "flush of an ARGB8565 buffer (the reference flushes lv_color_t only)");
     hipStream_t st = (hipStream_t)stream;
     BlendArgs a;
     lvgpu_area_t area;

@@ -36,6 +36,9 @@ struct BlendArgs {
     long long out_fs;
     int rot;               // LVGPU_ROT_*
     int swap_out;          // byte-swap pixels written to out
+    int raw_opa;           // dsc->opa as given (ARGB8565 destination path)
+    int raw_mode;          // dsc->blend_mode as given
+    int has_mask;          // a per-pixel alpha exists (mask buffer or source alpha)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2).  Remap the block id
@@ -348,6 +351,122 @@ __global__ __launch_bounds__(256) void k_blend_generic(BlendArgs a)
         uint32_t r = px_core(a, d, fg, m, idx, fnb);
         if(a.swap) r = px_swap16(r);
         *dp = (uint16_t)r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ARGB8565 destination (3 bytes per pixel: colour lo, colour hi, alpha) -- what lv_draw_sw_blend_basic draws into
+// when the display has screen_transp set (lv_draw_sw_blend.c:129-133, 177-184): fill_argb (:448-530) and map_argb
+// (:737-874) on top of set_px_argb (:378-402) / set_px_argb_blend (:404-446) and lv_color_mix_with_alpha
+// (lv_color.h:530-577).  One pixel per lane, byte accesses.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void px_mix_with_alpha(uint32_t bg, uint32_t bg_opa, uint32_t fg, uint32_t fg_opa,
+                                                  uint32_t & res, uint32_t & res_opa)
+{
+    if(fg_opa >= 253u || bg_opa <= 2u) {
+        res = fg;
+        res_opa = fg_opa;
+    }
+    else if(fg_opa <= 2u) {
+        res = bg;
+        res_opa = bg_opa;
+    }
+    else if(bg_opa >= 253u) {
+        res = px_mix(fg, bg, fg_opa);
+        res_opa = 255u;
+    }
+    else {
+        res_opa = 255u - (((255u - fg_opa) * (255u - bg_opa)) >> 8);
+        const uint32_t ratio = (fg_opa * 255u) / res_opa;
+        res = px_mix(fg, bg, ratio & 0xFFu);
+    }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
+{
+    const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if(idx >= area) return;
+    const uint32_t y = idx / (uint32_t)a.w, x = idx - y * (uint32_t)a.w;
+    const bool fill = SRC == SRC_FILL;
+    const uint32_t opa = (uint32_t)a.raw_opa;
+    const bool blended = !fill && a.raw_mode >= 1 && a.raw_mode <= 3;
+    for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
+        uint8_t * dp = reinterpret_cast<uint8_t *>(a.dst) + ((long long)f * a.dst_fs + (size_t)y * a.dst_stride + x) * 3;
+        uint32_t fg = a.color, m = 0;
+        const size_t sp = (size_t)y * a.src_stride + x;
+        if(SRC == SRC_RGB565) {
+            uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
+            fg = a.swap ? px_swap16(v) : v;
+        }
+        else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+            uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
+            fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+            m = v >> 24;
+        }
+        else if(SRC == SRC_ARGB8565) {
+            const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
+            uint32_t v = p[0] | (p[1] << 8);
+            fg = a.swap ? px_swap16(v) : v;
+            m = p[2];
+        }
+        if(a.mask) {
+            // fill_argb's "only the mask matters" loop (:494-505) never adds (mask_stride - w) at the end of a row:
+            // row y of the area reads mask[y*w + x]
+            const size_t mi = (fill && opa >= 253u) ? (size_t)y * a.w + x : (size_t)y * a.mask_stride + x;
+            m = a.mask[(long long)f * a.mask_fs + mi];
+        }
+        uint32_t o;
+        bool plain_store = false;
+        if(!a.has_mask) {
+            if(fill) {
+                o = opa;
+                plain_store = opa >= 253u;           // :465-477 writes colour and opa as they are
+            }
+            else o = opa >= 253u ? 255u : opa;       // :768-819
+        }
+        else if(fill) {
+            if(opa >= 253u) o = m;                   // :494-505
+            else {                                   // :507-528
+                if(m == 0u) continue;
+                o = m == 255u ? opa : (m * opa) >> 8;
+            }
+        }
+        else {
+            if(opa > 253u) o = m;                    // :824-843
+            else {                                   // :846-871
+                if(m == 0u) continue;
+                o = m >= 253u ? opa : (opa * m) >> 8;
+            }
+        }
+        uint32_t bg = dp[0] | (dp[1] << 8);
+        if(a.swap) bg = px_swap16(bg);
+        const uint32_t bg_opa = dp[2];
+        uint32_t res;
+        if(plain_store) {
+            res = fg;
+            dp[2] = (uint8_t)opa;
+        }
+        else if(blended) {                           // set_px_argb_blend
+            if(bg_opa <= 2u) continue;
+            if(o <= 2u) res = bg;
+            else {
+                uint32_t c = a.raw_mode == 1   ? px_blend_fn<BF_ADDITIVE>(fg, bg, a.swap)
+                             : a.raw_mode == 2 ? px_blend_fn<BF_SUBTRACTIVE>(fg, bg, a.swap)
+                                               : px_blend_fn<BF_MULTIPLY>(fg, bg, a.swap);
+                res = o == 255u ? c : px_mix(c, bg, o);
+            }
+        }
+        else {                                       // set_px_argb
+            uint32_t ro;
+            px_mix_with_alpha(bg, bg_opa, fg, o, res, ro);
+            dp[2] = (uint8_t)ro;
+            if(ro <= 2u) continue;
+        }
+        if(a.swap) res = px_swap16(res);
+        dp[0] = (uint8_t)(res & 0xFFu);
+        dp[1] = (uint8_t)(res >> 8);
     }
 }
 

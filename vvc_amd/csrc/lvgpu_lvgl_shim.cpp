@@ -64,7 +64,7 @@ void ensure_capacity(ShimCtx * s, size_t px)
     if(s->d_src) HIP_OR_DIE(hipFree(s->d_src));
     if(s->d_mask) HIP_OR_DIE(hipFree(s->d_mask));
     size_t cap = px < 65536 ? 65536 : px;
-    HIP_OR_DIE(hipMalloc(&s->d_dst, cap * 2));
+    HIP_OR_DIE(hipMalloc(&s->d_dst, cap * 3));  // 3 bytes per pixel when the screen is transparent (ARGB8565)
     HIP_OR_DIE(hipMalloc(&s->d_src, cap * 2));
     HIP_OR_DIE(hipMalloc(&s->d_mask, cap));
     s->cap_px = cap;
@@ -144,10 +144,10 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
     lvgpu_lv_disp_drv_t * drv = s->drv;
 
-    // Requests outside this library's coverage go to the host's own lv_draw_sw_blend_basic, the convention of
-    // every LVGL GPU back-end (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130,207): a custom
-    // set_px_cb, and the ARGB8565 destination layout of a transparent screen.
-    if(drv->set_px_cb != nullptr || drv->screen_transp) {
+    // A request outside this library's coverage goes to the host's own lv_draw_sw_blend_basic, the convention of
+    // every LVGL GPU back-end (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130,207): a display
+    // with a custom set_px_cb, whose pixel format only that callback knows.
+    if(drv->set_px_cb != nullptr) {
         g_blend_delegated++;
         if(g_sw_blend_basic) g_sw_blend_basic(draw_ctx, dsc);
         else {
@@ -172,8 +172,9 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     if(a.x1 > a.x2 || a.y1 > a.y2) return;
     const int w = aw(&a), h = ah(&a);
 
-    uint16_t * dest = reinterpret_cast<uint16_t *>(draw_ctx->buf) +
-                      (size_t)dest_stride * (a.y1 - draw_ctx->buf_area->y1) + (a.x1 - draw_ctx->buf_area->x1);
+    const size_t dbpp = drv->screen_transp ? 3 : 2;  // lv_draw_sw_blend.c:126-133
+    uint8_t * dest = reinterpret_cast<uint8_t *>(draw_ctx->buf) +
+                     ((size_t)dest_stride * (a.y1 - draw_ctx->buf_area->y1) + (a.x1 - draw_ctx->buf_area->x1)) * dbpp;
     const uint16_t * src = dsc->src_buf;
     int src_stride = 0;
     if(src) {
@@ -193,16 +194,21 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     const size_t px = (size_t)w * h;
     ensure_capacity(s, px);
     hipStream_t st = s->stream;
-    const bool dst_needed = !(src == nullptr && mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0) &&
-                            !(src != nullptr && mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0);
-    if(dst_needed)
-        HIP_OR_DIE(hipMemcpy2DAsync(s->d_dst, (size_t)w * 2, dest, (size_t)dest_stride * 2, (size_t)w * 2, h,
+    const bool overwrite = mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0 && !drv->screen_transp;
+    if(!overwrite)  // every other case reads the destination
+        HIP_OR_DIE(hipMemcpy2DAsync(s->d_dst, (size_t)w * dbpp, dest, (size_t)dest_stride * dbpp, (size_t)w * dbpp, h,
                                     hipMemcpyHostToDevice, st));
     if(src)
         HIP_OR_DIE(hipMemcpy2DAsync(s->d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h,
                                     hipMemcpyHostToDevice, st));
-    if(mask)
-        HIP_OR_DIE(hipMemcpy2DAsync(s->d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, h, hipMemcpyHostToDevice, st));
+    if(mask) {
+        if(drv->screen_transp && src == nullptr && dsc->opa >= 253)
+            // fill_argb's opaque masked loop walks the mask as ONE run of w*h bytes (lv_draw_sw_blend.c:494-505: the
+            // pointer is never advanced by mask_stride - w), so that run is what has to be staged
+            HIP_OR_DIE(hipMemcpyAsync(s->d_mask, mask, px, hipMemcpyHostToDevice, st));
+        else
+            HIP_OR_DIE(hipMemcpy2DAsync(s->d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, h, hipMemcpyHostToDevice, st));
+    }
 
     lvgpu_blend_batch_t b;
     memset(&b, 0, sizeof(b));
@@ -221,13 +227,14 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     b.opa = dsc->opa;
     b.blend_mode = dsc->blend_mode;
     b.color_16_swap = (uint8_t)g_swap;
+    b.dst_argb8565 = drv->screen_transp ? 1 : 0;
     int rc = lvgpu_blend_batch(&b, st);
     if(rc != LVGPU_OK) {
         fprintf(stderr, "lvgpu: lvgpu_blend_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
         g_errors++;
         abort();
     }
-    HIP_OR_DIE(hipMemcpy2DAsync(dest, (size_t)dest_stride * 2, s->d_dst, (size_t)w * 2, (size_t)w * 2, h,
+    HIP_OR_DIE(hipMemcpy2DAsync(dest, (size_t)dest_stride * dbpp, s->d_dst, (size_t)w * dbpp, (size_t)w * dbpp, h,
                                 hipMemcpyDeviceToHost, st));
     // src_buf / mask_buf may be reused by the caller as soon as we return, and the CPU reads the draw buffer.
     HIP_OR_DIE(hipStreamSynchronize(st));

@@ -67,7 +67,8 @@ __device__ __forceinline__ uint32_t px_to32(uint32_t c)
 }
 
 // color_blend_true_color_additive / _subtractive / _multiply, lv_draw_sw_blend.c:950-1050, the part before the
-// final lv_color_mix.  swap selects the LV_COLOR_16_SWAP 1 build, whose subtractive green ADDS (:1015-1018).
+// final lv_color_mix.  swap selects the LV_COLOR_16_SWAP 1 build, whose subtractive green ADDS (:1015-1018) and whose
+// multiply green is affected by a double macro evaluation (:1040).
 template <int BF>
 __device__ __forceinline__ uint32_t px_blend_fn(uint32_t fg, uint32_t bg, int swap)
 {
@@ -89,6 +90,13 @@ __device__ __forceinline__ uint32_t px_blend_fn(uint32_t fg, uint32_t bg, int sw
         r = (fr * br) >> 5;
         b = (fb * bb) >> 5;
         g = (fgn * bgn) >> 6;
+        if(swap) {
+            // LV_COLOR_SET_G16 of the swapped build (lv_color.h:134) evaluates its argument twice; the second
+            // evaluation (green_l) sees the foreground green with the freshly stored high bits (:1040).
+            const uint32_t gh = (g >> 3) & 7u;
+            const uint32_t g2 = (((gh << 3) + (fgn & 7u)) * bgn) >> 6;
+            g = (gh << 3) | (g2 & 7u);
+        }
     }
     return (r << 11) | (g << 5) | b;
 }
@@ -129,7 +137,7 @@ __device__ __forceinline__ uint32_t px_fill_premult(const PremultFill & pf, uint
     return px_mix_premult(pf, d);
 }
 
-// counter-based generator shared with the CPU oracle (splitmix64 finaliser)
+// finaliser of splitmix64: the counter-based generator behind lvgpu_synth / lvgpu_checksum
 __device__ __forceinline__ uint64_t fin64(uint64_t z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

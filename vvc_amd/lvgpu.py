@@ -58,14 +58,18 @@ def _frame_stride_bytes(t, n_frames, frame_dims):
 class DrawCtx:
     """lv_draw_ctx_t over a batch: buf is [n_frames, H, W] 16-bit pixels in device memory."""
 
-    def __init__(self, buf, buf_area=None, clip_area=None, color_16_swap=1):
+    def __init__(self, buf, buf_area=None, clip_area=None, color_16_swap=1, screen_transp=0):
         _dev(buf, "buf")
-        if buf.dim() != 3 or buf.element_size() != 2:
+        self.screen_transp = 1 if screen_transp else 0
+        if self.screen_transp:  # ARGB8565 destination: [n_frames, H, W, 3] bytes (lv_draw_sw_blend.c:129-133)
+            if buf.dim() != 4 or buf.shape[3] != 3 or buf.element_size() != 1:
+                raise ValueError("with screen_transp buf must be [n_frames, H, W, 3] bytes")
+        elif buf.dim() != 3 or buf.element_size() != 2:
             raise ValueError("buf must be [n_frames, H, W] with 2-byte elements")
         if buf.shape[0] and not buf[0].is_contiguous():
             raise ValueError("each frame must be contiguous")
         self.buf = buf
-        n, h, w = buf.shape
+        n, h, w = buf.shape[:3]
         self.buf_area = Area.of(buf_area) if buf_area is not None else Area(0, 0, w - 1, h - 1)
         if self.buf_area.w != w or self.buf_area.h != h:
             raise ValueError("buf_area does not match the buffer shape")
@@ -100,6 +104,9 @@ def _fill_batch(ctx, dsc):
     b = BlendBatch()
     b.dst = ctx.buf.data_ptr()
     b.dst_frame_stride = ctx.buf.stride(0) if ctx.n_frames > 1 else ctx.buf.shape[1] * ctx.buf.shape[2]
+    if ctx.screen_transp:
+        b.dst_frame_stride = (ctx.buf.stride(0) // 3) if ctx.n_frames > 1 else ctx.buf.shape[1] * ctx.buf.shape[2]
+        b.dst_argb8565 = 1
     b.buf_area, b.clip_area, b.blend_area = ctx.buf_area, ctx.clip_area, dsc.blend_area
     b.n_frames = ctx.n_frames
     b.src_format = dsc.src_format
