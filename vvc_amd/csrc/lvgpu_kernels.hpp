@@ -154,6 +154,15 @@ __device__ __forceinline__ uint4 blend_group(const BlendArgs & a, uint4 d, const
     return make_uint4(rw[0], rw[1], rw[2], rw[3]);
 }
 
+// The panel image is written once and never read back by these kernels: a non-temporal store keeps it from
+// displacing the draw-buffer lines that are still being read-modified-written in L2 (measured +2 % on the fused path).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_streaming(uint16_t * p, uint4 v)
+{
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(p));
+}
+
 __device__ __forceinline__ uint4 swap_group(uint4 v)
 {
     return make_uint4(px_swap16x2(v.x), px_swap16x2(v.y), px_swap16x2(v.z), px_swap16x2(v.w));
@@ -213,8 +222,8 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
             if(a.out) {
                 uint16_t * out = a.out + (long long)f * a.out_fs;
                 if(a.swap_out) r = swap_group(r);
-                if(a.rot == 2) *reinterpret_cast<uint4 *>(out + (size_t)(gpf - 1 - g) * 8) = reverse_group(r);
-                else *reinterpret_cast<uint4 *>(out + (size_t)g * 8) = r;
+                if(a.rot == 2) store_streaming(out + (size_t)(gpf - 1 - g) * 8, reverse_group(r));
+                else store_streaming(out + (size_t)g * 8, r);
             }
         }
     }
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
             if(X < W && yb < H) {
                 uint4 v = lds[wave][xl * 8 + (c ^ k)];
                 size_t o = a.rot == 1 ? (size_t)X * H + (size_t)(H - 8 - yb) : (size_t)(W - 1 - X) * H + (size_t)yb;
-                *reinterpret_cast<uint4 *>(out + o) = v;
+                store_streaming(out + o, v);
             }
         }
     }
