@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--swap", type=int, default=1, help="LV_COLOR_16_SWAP of the buffers (firmware: 1)")
     ap.add_argument("--mask", default="ui", choices=["ui", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eighth", action="store_true", help="skip the 32-CU (1/8 of the CUs) measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -84,6 +85,31 @@ def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
     }
 
 
+def eighth_gpu(args, step_on, n_px, bpp):
+    """The same launch restricted to 32 of the 256 CUs (hipExtStreamCreateWithCUMask), i.e. 1/8 of the GPU's compute.
+    The runtime deals CU-mask bits round-robin over the XCDs and rejects a mask that leaves an XCD empty, so the
+    32 CUs are 4 per XCD; the memory system behind them is the whole device's."""
+    try:
+        ms = lvgpu.MaskedStream(range(32))
+    except lvgpu.LvgpuError as e:
+        return {"error": str(e)}
+    census = ms.census()
+    for _ in range(2):
+        step_on(ms.handle)
+    ms.synchronize()
+    k = 5
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step_on(ms.handle)
+    ms.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    ms.close()
+    gbs = bpp * n_px / dt / 1e9
+    return {"cus": 32, "workgroups_per_xcd": census, "value": round(n_px / dt / 1e6, 1), "unit": "Mpx/s",
+            "achieved_GBs": round(gbs, 1), "nominal_peak_GBs": HBM_PEAK_GBS / 8,
+            "frac_of_nominal": round(gbs / (HBM_PEAK_GBS / 8), 4)}
+
+
 def main():
     args = parse()
     rank, world, local_rank, dist = sharding.init("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
@@ -107,13 +133,13 @@ def main():
     dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
     swap_bytes = 0 if args.swap else 1
 
-    def step():
+    def step(stream=None):
         if args.workload == "blend_flush":
-            lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out)
+            lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
         elif args.workload == "blend":
-            lvgpu.lv_draw_sw_blend(ctx, dsc)
+            lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
         else:
-            lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out)
+            lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out, stream=stream)
 
     # first step on fresh inputs: keep the first frames for the CPU cross-check
     step()
@@ -138,6 +164,11 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     dt, ev_ms = sharding.max_over_ranks(dist, [dt, ev_ms])
+
+    eighth = None
+    if rank == 0 and world == 1 and not args.no_eighth:
+        eighth = eighth_gpu(args, lambda st: step(st.value), px * n, BYTES_PER_PX[args.workload])
+        torch.cuda.synchronize()
 
     if rank == 0:
         total_px = px * n * world * args.steps
@@ -176,6 +207,8 @@ def main():
             },
             "pct_hbm_peak": round(100 * achieved / HBM_PEAK_GBS, 2),
         }
+        if eighth is not None:
+            res["eighth_gpu"] = eighth
         if world == 1 and not args.no_cpu_baseline and args.workload != "rotate":
             res["cpu_baseline"] = cpu_baseline(args, W, H, d_first, o_first)
         print(json.dumps(res), flush=True)

@@ -216,6 +216,14 @@ int lvgpu_synth(void * dev_out, int kind, uint64_t seed, uint64_t first_index, s
 int lvgpu_checksum(const void * dev_in, int elem_bytes, uint64_t first_index, size_t count, uint64_t * dev_sum64,
                    void * stream);
 
+/* A stream restricted to the compute units whose bits are set in mask_words (hipExtStreamCreateWithCUMask): used
+ * to measure the path on a fraction of the GPU, e.g. the 32 CUs of one XCD ("1/8 GPU"). */
+int lvgpu_stream_create_cu_mask(void ** stream, const uint32_t * mask_words, int n_words);
+int lvgpu_stream_destroy(void * stream);
+/* Launches n_blocks workgroups on `stream` and adds, per XCD id (0..7), the number of workgroups that ran there to
+ * dev_counts8[0..7] (device memory, zero it first): tells which XCDs a CU mask actually selects. */
+int lvgpu_xcc_census(uint32_t * dev_counts8, int n_blocks, void * stream);
+
 /* Name of the kernel the last launch on this thread used (diagnostics / tests that assert the fast path ran). */
 const char * lvgpu_last_kernel(void);
 

@@ -108,6 +108,9 @@ def lib():
         "lvgpu_buffer_copy_batch": (C.c_int, [vp, i64, i32, Area, vp, i64, i32, Area, i32, vp]),
         "lvgpu_synth": (C.c_int, [vp, C.c_int, u64, u64, sz, vp]),
         "lvgpu_checksum": (C.c_int, [vp, C.c_int, u64, sz, vp, vp]),
+        "lvgpu_stream_create_cu_mask": (C.c_int, [C.POINTER(vp), vp, C.c_int]),
+        "lvgpu_stream_destroy": (C.c_int, [vp]),
+        "lvgpu_xcc_census": (C.c_int, [vp, C.c_int, vp]),
         "lvgpu_lvgl_bind": (None, [vp, vp, vp]),
         "lvgpu_lvgl_set_color_16_swap": (None, [C.c_int]),
         "lvgpu_draw_ctx_init": (None, [vp, vp]),

@@ -532,4 +532,25 @@ int lvgpu_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, ui
     return LVGPU_OK;
 }
 
+int lvgpu_stream_create_cu_mask(void ** stream, const uint32_t * mask_words, int n_words)
+{
+    if(!stream || !mask_words || n_words <= 0) return fail(LVGPU_ERR_ARG, "bad arguments");
+    hipStream_t st;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+    *stream = st;
+    return LVGPU_OK;
+}
+int lvgpu_stream_destroy(void * stream)
+{
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return LVGPU_OK;
+}
+int lvgpu_xcc_census(uint32_t * dev_counts8, int n_blocks, void * stream)
+{
+    if(!dev_counts8 || n_blocks <= 0) return fail(LVGPU_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(k_xcc_census, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, dev_counts8);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+
 }  // extern "C"

@@ -620,4 +620,16 @@ __global__ void k_checksum(const void * in, int elem_bytes, uint64_t first, size
     if((threadIdx.x & 63) == 0) atomicAdd(sum, (unsigned long long)s);
 }
 
+// one count per workgroup, binned by the XCD it ran on (HW_REG_XCC_ID, bits 3:0)
+__global__ void k_xcc_census(uint32_t * counts8)
+{
+    if(threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        atomicAdd(&counts8[id & 7u], 1u);
+    }
+    // give the dispatcher time to spread workgroups over every CU the queue may use
+    for(int i = 0; i < 200; i++) __builtin_amdgcn_s_sleep(20);
+}
+
 }  // namespace lvgpu

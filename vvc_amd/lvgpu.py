@@ -37,6 +37,8 @@ def _stream(stream):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
     if isinstance(stream, torch.cuda.Stream):
         return C.c_void_p(stream.cuda_stream)
+    if isinstance(stream, C.c_void_p):
+        return stream
     return C.c_void_p(int(stream))
 
 
@@ -225,3 +227,32 @@ def checksum(t, first_index=0, stream=None):
     check(_lib.lib().lvgpu_checksum(t.data_ptr(), t.element_size(), first_index, t.numel(), acc.data_ptr(),
                                      _stream(stream)))
     return int(acc.item()) & 0xFFFFFFFFFFFFFFFF
+
+
+class MaskedStream:
+    """A HIP stream restricted to a set of compute units (measurement support: "1/8 GPU")."""
+
+    def __init__(self, cu_bits, total_cus=256):
+        words = (total_cus + 31) // 32
+        arr = (C.c_uint32 * words)()
+        for b in cu_bits:
+            arr[b // 32] |= 1 << (b % 32)
+        self.handle = C.c_void_p()
+        check(_lib.lib().lvgpu_stream_create_cu_mask(C.byref(self.handle), arr, words))
+        self.cu_bits = list(cu_bits)
+
+    def synchronize(self):
+        check(_lib.lib().lvgpu_stream_synchronize(self.handle))
+
+    def census(self, n_blocks=4096):
+        """Workgroups per XCD for a launch on this stream."""
+        counts = torch.zeros(8, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        check(_lib.lib().lvgpu_xcc_census(counts.data_ptr(), n_blocks, self.handle))
+        self.synchronize()
+        return counts.cpu().tolist()
+
+    def close(self):
+        if self.handle:
+            check(_lib.lib().lvgpu_stream_destroy(self.handle))
+            self.handle = C.c_void_p()
