@@ -238,12 +238,13 @@ struct LaunchArgbDst {
     }
 };
 template <int SRC>
-struct LaunchGeneric {
+struct LaunchRows {
     static int run(const BlendArgs & a, hipStream_t st)
     {
-        const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
-        dim3 grid((area + 255) / 256, std::min<uint32_t>(a.n_frames, 65535));
-        hipLaunchKernelGGL(k_blend_generic<SRC>, grid, dim3(256), 0, st, a);
+        const uint32_t gmax = ((uint32_t)a.w + 7 + 7) / 8;  // groups per row for the worst row alignment
+        const uint64_t lanes = (uint64_t)gmax * (uint32_t)a.h;
+        dim3 grid((uint32_t)((lanes + 255) / 256), std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_blend_rows<SRC>, grid, dim3(256), 0, st, a, gmax);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
@@ -287,8 +288,8 @@ int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
         rc = dispatch_src<LaunchLinear>(fmt, a, st);
     }
     else {
-        g_last_kernel = "k_blend_generic";
-        rc = dispatch_src<LaunchGeneric>(fmt, a, st);
+        g_last_kernel = "k_blend_rows";
+        rc = dispatch_src<LaunchRows>(fmt, a, st);
     }
     if(scratch) HIP_TRY(hipFreeAsync(scratch, st));
     return rc;

@@ -7,7 +7,8 @@
 //   k_tile         : blend and/or 90/270-degree rotation; a wave owns a 64x64-pixel tile, each lane an 8x8 block,
 //                    transposes it in registers and exchanges it through wave-private LDS so that both the loads
 //                    and the rotated stores are 128-byte contiguous per 8 lanes
-//   k_blend_generic / k_rotate_generic : one pixel per lane, any geometry or alignment
+//   k_blend_rows   : blend over any rectangle/alignment: 16-byte-aligned destination groups, scalar row edges
+//   k_rotate_generic : rotation for sizes that are not multiples of 8, one pixel per lane
 #pragma once
 #include "lvgpu_px.hpp"
 
@@ -325,41 +326,96 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// generic (any rectangle, any alignment): one pixel per lane.
+// k_blend_rows: any rectangle, any alignment.  A lane owns one 16-byte-aligned group of 8 destination pixels of one
+// row of the area.  Groups that lie completely inside the area are processed as vectors (aligned 16-B destination
+// access; source and mask rows start anywhere, so they are fetched with under-aligned wide loads, which gfx950
+// executes as single global_load_dwordx4/x2); the at most two partial groups per row go pixel by pixel so that
+// nothing outside the area is ever written.
 // ---------------------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+
 template <int SRC>
-__global__ __launch_bounds__(256) void k_blend_generic(BlendArgs a)
+__device__ __forceinline__ void load_src_unaligned(const void * base, long long px, uint32_t * sw)
 {
-    const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+    if(SRC == SRC_RGB565) {
+        u32x4_a2 v = *reinterpret_cast<const u32x4_a2 *>(reinterpret_cast<const uint16_t *>(base) + px);
+        sw[0] = v.x; sw[1] = v.y; sw[2] = v.z; sw[3] = v.w;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        const u32x4_a4 * p = reinterpret_cast<const u32x4_a4 *>(reinterpret_cast<const uint32_t *>(base) + px);
+        u32x4_a4 v0 = p[0], v1 = p[1];
+        sw[0] = v0.x; sw[1] = v0.y; sw[2] = v0.z; sw[3] = v0.w;
+        sw[4] = v1.x; sw[5] = v1.y; sw[6] = v1.z; sw[7] = v1.w;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const u32x2_a1 * p = reinterpret_cast<const u32x2_a1 *>(reinterpret_cast<const uint8_t *>(base) + px * 3);
+        u32x2_a1 v0 = p[0], v1 = p[1], v2 = p[2];
+        sw[0] = v0.x; sw[1] = v0.y; sw[2] = v1.x; sw[3] = v1.y; sw[4] = v2.x; sw[5] = v2.y;
+    }
+}
+
+// one pixel at area-relative (x, y) of frame f, scalar accesses
+template <int SRC>
+__device__ __forceinline__ void blend_one_px(const BlendArgs & a, uint32_t f, uint32_t x, uint32_t y, uint32_t fnb)
+{
+    uint16_t * dp = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride + x;
+    uint32_t d = *dp;
+    if(a.swap) d = px_swap16(d);
+    uint32_t fg = a.color, m = 0;
+    const size_t sp = (size_t)y * a.src_stride + x;
+    if(SRC == SRC_RGB565) {
+        uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
+        fg = a.swap ? px_swap16(v) : v;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
+        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+        m = v >> 24;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
+        uint32_t v = p[0] | (p[1] << 8);
+        fg = a.swap ? px_swap16(v) : v;
+        m = p[2];
+    }
+    if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
+    uint32_t r = px_core(a, d, fg, m, y * (uint32_t)a.w + x, fnb);
+    if(a.swap) r = px_swap16(r);
+    *dp = (uint16_t)r;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax)
+{
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if(idx >= area) return;
-    const uint32_t y = idx / (uint32_t)a.w, x = idx - y * (uint32_t)a.w;
+    const uint32_t y = idx / gmax, k = idx - y * gmax;
+    if(y >= (uint32_t)a.h) return;
     for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
-        uint16_t * dp = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride + x;
-        uint32_t d = *dp;
-        if(a.swap) d = px_swap16(d);
-        uint32_t fg = a.color, m = 0;
-        const size_t sp = (size_t)y * a.src_stride + x;
-        if(SRC == SRC_RGB565) {
-            uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
-            fg = a.swap ? px_swap16(v) : v;
-        }
-        else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
-            uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
-            fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
-            m = v >> 24;
-        }
-        else if(SRC == SRC_ARGB8565) {
-            const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
-            uint32_t v = p[0] | (p[1] << 8);
-            fg = a.swap ? px_swap16(v) : v;
-            m = p[2];
-        }
-        if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
+        uint16_t * row = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride;
+        const int off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7u);  // row start within its 16-byte group
+        const int x_lo = (int)k * 8 - off;
+        if(x_lo >= a.w) continue;
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-        uint32_t r = px_core(a, d, fg, m, idx, fnb);
-        if(a.swap) r = px_swap16(r);
-        *dp = (uint16_t)r;
+        if(x_lo >= 0 && x_lo + 8 <= a.w) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(row + x_lo);
+            uint32_t sw[SrcWords<SRC>::N];
+            uint2 mk = make_uint2(0, 0);
+            if(SRC != SRC_FILL)
+                load_src_unaligned<SRC>(a.src, (long long)f * a.src_fs + (long long)y * a.src_stride + x_lo, sw);
+            if(a.mask) {
+                u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(a.mask + (long long)f * a.mask_fs + (size_t)y * a.mask_stride + x_lo);
+                mk = make_uint2(v.x, v.y);
+            }
+            *reinterpret_cast<uint4 *>(row + x_lo) = blend_group<SRC>(a, d, sw, mk, y * (uint32_t)a.w + (uint32_t)x_lo, fnb);
+        }
+        else {
+            for(int j = 0; j < 8; j++) {
+                const int x = x_lo + j;
+                if(x >= 0 && x < a.w) blend_one_px<SRC>(a, f, (uint32_t)x, y, fnb);
+            }
+        }
     }
 }
 
