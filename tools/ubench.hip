@@ -173,9 +173,9 @@ int main(int argc, char ** argv)
         a.rot = 1;
         const uint32_t tiles_x = (W + 63) / 64, tiles_y = (H + 63) / 64, tpf = tiles_x * tiles_y;
         const uint32_t n_tiles = tpf * n_frames;
-        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_ARGB8888>, dim3((n_tiles + 3) / 4), dim3(256), 0, 0, a, W, H, tiles_x, tpf, n_tiles); });
+        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_ARGB8888>, dim3((n_tiles + 3) / 4), dim3(256), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
         report("k_tile<ARGB8888> fused rot90 (10 B/px)", px * 10.0, ms);
-        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_COPY>, dim3((n_tiles + 3) / 4), dim3(256), 0, 0, a, W, H, tiles_x, tpf, n_tiles); });
+        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_COPY>, dim3((n_tiles + 3) / 4), dim3(256), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
         report("k_tile<COPY> rot90 (4 B/px)", px * 4.0, ms);
     }
     run_variants(a, W, H, n_frames, px, T, report);

@@ -220,8 +220,8 @@ struct LaunchTile {
         const uint32_t tpf = tiles_x * tiles_y;
         const uint64_t n_tiles = (uint64_t)tpf * a.n_frames;
         if(n_tiles > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, st, a, W, H, tiles_x, tpf,
-                           (uint32_t)n_tiles);
+        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), 0, st, a, W, H, tiles_x, tiles_y,
+                           tpf, (uint32_t)n_tiles);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }

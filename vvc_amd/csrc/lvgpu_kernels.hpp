@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
 constexpr int TILE = 64;
 
 template <int SRC>
-__global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tpf, uint32_t n_tiles)
+__global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpf,
+                                              uint32_t n_tiles)
 {
     __shared__ uint4 lds[4][512];
     const int lane = threadIdx.x & 63;
@@ -252,7 +253,19 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
     const bool live = wt < n_tiles;
     const uint32_t f = live ? wt / tpf : 0;
     const uint32_t t = live ? wt - f * tpf : 0;
-    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    // Tiles of a frame are visited in blocks of 8x8 tiles (512x512 px), row-major inside a block: consecutive waves
+    // then read 1 KB runs of the same source rows and complete 1 KB runs of the same panel rows while those lines
+    // are still in L2 (matters for canvases much larger than the L2; a 480x320 frame is a single block).
+    uint32_t tx, ty;
+    {
+        const uint32_t sy = t / (8u * tiles_x), r = t - sy * 8u * tiles_x;
+        const uint32_t th = min(8u, tiles_y - 8u * sy);
+        const uint32_t sx = r / (8u * th), r2 = r - sx * 8u * th;
+        const uint32_t tw = min(8u, tiles_x - 8u * sx);
+        const uint32_t qy = r2 / tw;
+        ty = sy * 8u + qy;
+        tx = sx * 8u + (r2 - qy * tw);
+    }
     constexpr bool BLEND = SRC != SRC_COPY;
 
     const int bx = lane & 7, by = lane >> 3;
