@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
-@pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3)])
+@pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3),
+                                   (96, 200), (64, 40), (200, 344), (136, 72), (8, 8)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -17,7 +18,8 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     frames = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
     out = gpu.flush_rotate(to_dev(frames), rot, swap_bytes=swap_bytes)
     fast = W % 8 == 0 and H % 8 == 0
-    assert gpu.last_kernel() == (("k_tile" if rot in (1, 3) else "k_blend_linear") if fast else "k_rotate_generic")
+    quarter = ("k_strip" if H % 32 else "k_tile")  # heights off the 32-px grid take the column-strip kernel
+    assert gpu.last_kernel() == ((quarter if rot in (1, 3) else "k_blend_linear") if fast else "k_rotate_generic")
     got = to_np(out, np.uint16).reshape(N, -1)
     for f in range(N):
         exp = oracle.flush_frame(frames[f], W, H, rot, swap_bytes)
@@ -74,6 +76,45 @@ def test_blend_flush_fused(gpu, oracle, rot, swap, fmt):
         for f in range(N):
             exp = oracle.flush_frame(exp_dst[f], W, H, rot, swap_bytes)
             assert np.array_equal(got[f], exp), "panel image, opa %d frame %d" % (opa, f)
+
+
+@pytest.mark.parametrize("rot", [1, 3])
+@pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216)])
+def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
+    """Heights that are not a multiple of 32 px: fused blend + rotation through the column-strip kernel."""
+    W, H = shape
+    N = 3
+    rng = np.random.default_rng(W + H + rot)
+    area = (0, 0, W - 1, H - 1)
+    for fmt, opa in ((2, 255), (1, 200), (0, 128)):
+        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        dst[0, : H // 3] = 0
+        color = int(rng.integers(0, 65536))
+        mask = None
+        if fmt == 2:
+            src = (rng.integers(0, 1 << 32, (N, H, W), dtype=np.uint32) & 0xFFFFFF) | (
+                rand_mask(rng, (N, H, W)).astype(np.uint32) << 24)
+        elif fmt == 1:
+            src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            mask = rand_mask(rng, (N, H, W))
+        else:
+            src = None
+        exp_dst = dst.copy()
+        for f in range(N):
+            if fmt == 2:
+                oracle.img_blend(exp_dst[f], area, area, area, src[f], fmt, opa, 1, W)
+            else:
+                oracle.blend(exp_dst[f], area, area, area, src=None if src is None else src[f], color=color,
+                             mask=None if mask is None else mask[f], opa=opa, swap=1)
+        d = to_dev(dst)
+        dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
+        out = gpu.blend_flush(gpu.DrawCtx(d), dsc, rot)
+        assert gpu.last_kernel() == "k_strip(fused)"
+        assert np.array_equal(to_np(d, np.uint16), exp_dst)
+        got = to_np(out, np.uint16).reshape(N, -1)
+        for f in range(N):
+            assert np.array_equal(got[f], oracle.flush_frame(exp_dst[f], W, H, rot, 0)), (fmt, f)
 
 
 def test_blend_flush_unfused_shapes(gpu, oracle):

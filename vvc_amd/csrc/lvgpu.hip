@@ -238,6 +238,24 @@ struct LaunchArgbDst {
     }
 };
 template <int SRC>
+struct LaunchStrip {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const int W = a.w, H = a.h;
+        const uint32_t strips_x = (W + TILE - 1) / TILE;
+        const uint64_t n_strips = (uint64_t)strips_x * a.n_frames;
+        if(n_strips > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_strip<SRC>, dim3((uint32_t)((n_strips + 3) / 4)), dim3(256), 0, st, a, W, H, strips_x,
+                           (uint32_t)n_strips);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+// Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
+// the tile kernel's output runs degrade; the strip kernel writes whole lines regardless.
+inline bool wants_strip(const BlendArgs & a) { return (a.h % 32) != 0; }
+
+template <int SRC>
 struct LaunchRows {
     static int run(const BlendArgs & a, hipStream_t st)
     {
@@ -313,6 +331,10 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
     const bool out_ok = aligned(out, 16) && (out_fs % 8) == 0;
     const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
     if(out_ok && transposing && tile_ok(a, SRC_COPY)) {
+        if(wants_strip(a)) {
+            g_last_kernel = "k_strip";
+            return LaunchStrip<SRC_COPY>::run(a, st);
+        }
         g_last_kernel = "k_tile";
         return LaunchTile<SRC_COPY>::run(a, st);
     }
@@ -445,7 +467,11 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
             uint32_t * scratch = nullptr;
             int rc = prepare_first_nb(a, st, &scratch);
             if(rc != LVGPU_OK) return rc;
-            if(transposing) {
+            if(transposing && wants_strip(a)) {
+                g_last_kernel = "k_strip(fused)";
+                rc = dispatch_src<LaunchStrip>(b.src_format, a, st);
+            }
+            else if(transposing) {
                 g_last_kernel = "k_tile(fused)";
                 rc = dispatch_src<LaunchTile>(b.src_format, a, st);
             }

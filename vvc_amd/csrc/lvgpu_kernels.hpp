@@ -164,6 +164,16 @@ __device__ __forceinline__ void store_streaming(uint16_t * p, uint4 v)
     __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(p));
 }
 
+// The LDS exchange areas are private to one wavefront.  A wave executes its LDS instructions in order, so a read
+// that follows a write in program order sees it; all that is needed is to keep the compiler from reordering the
+// two, which this does (no s_barrier: the waves of a block never wait for each other).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint4 swap_group(uint4 v)
 {
     return make_uint4(px_swap16x2(v.x), px_swap16x2(v.y), px_swap16x2(v.z), px_swap16x2(v.w));
@@ -320,7 +330,7 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
             lds[wave][xl * 8 + (by ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
-    __syncthreads();
+    __syncthreads();  // a block barrier rather than a wave fence: keeping the block's waves in step measured 2 % faster
     if(live && a.out) {
         uint16_t * out = a.out + (long long)f * a.out_fs;
         const int rr = lane >> 3, c = lane & 7;
@@ -335,6 +345,130 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
                 store_streaming(out + o, v);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_strip: the 90/270-degree path for frames whose height is not a multiple of 32 pixels.  There the panel rows
+// (2*H bytes each) start on 16/32/48-byte boundaries, a tile's 128-byte output runs fall apart into pieces smaller
+// than 64 bytes, and such pieces are written at a fraction of the full-line rate.  Here a wave owns a whole column
+// strip (64 columns x H rows) and walks it in 64-row steps in the direction of ascending panel addresses.  The
+// transposed 8-pixel chunks go into a 16-slot ring per panel row in LDS (slot = absolute chunk index mod 16), and
+// after every step each row emits the one 128-byte line that has just become complete, so every store is a whole,
+// aligned line; only the first and last line of a panel row (shared with its neighbour rows) are partial.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32_t strips_x, uint32_t n_strips)
+{
+    __shared__ uint4 ring[4][64 * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t ws = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
+    if(ws >= n_strips) return;  // no block-wide barrier below: a wave may leave on its own
+    const uint32_t f = ws / strips_x;
+    const uint32_t sx = ws - f * strips_x;
+    constexpr bool BLEND = SRC != SRC_COPY;
+    const bool r90 = a.rot == 1;
+    const int hc = H >> 3;                       // chunks (8 px) per panel row
+    const int n_it = (H + TILE - 1) / TILE;
+    const int bx = lane & 7, by = lane >> 3;
+    const int x0 = sx * TILE + bx * 8;
+    uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+    const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+    const long long src_px0 = (long long)f * a.src_fs;
+    const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+    uint16_t * out = a.out + (long long)f * a.out_fs;
+
+    uint4 d[8];
+    uint2 mk[8];
+    uint32_t sw[8][SrcWords<SRC>::N];
+    // rows of step `it`: rot90 walks from the bottom of the frame up, rot270 from the top down
+    auto first_row = [&](int it) { return (r90 ? H - TILE * (it + 1) : TILE * it) + by * 8; };
+    auto fetch = [&](int y0) {
+#pragma unroll
+        for(int i = 0; i < 8; i++) {
+            const size_t p = (size_t)(y0 + i) * W + x0;
+            d[i] = *reinterpret_cast<const uint4 *>(dst + p);
+            mk[i] = make_uint2(0, 0);
+            if(BLEND) {
+                if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
+                if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
+            }
+        }
+    };
+    int y0 = first_row(0);
+    bool inside = x0 < W && y0 >= 0 && y0 + 8 <= H;
+    if(inside) fetch(y0);
+
+    for(int it = 0; it < n_it; it++) {
+        uint4 r[8];
+        if(inside) {
+#pragma unroll
+            for(int i = 0; i < 8; i++) {
+                r[i] = d[i];
+                if(BLEND) {
+                    const size_t p = (size_t)(y0 + i) * W + x0;
+                    r[i] = blend_group<SRC>(a, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    *reinterpret_cast<uint4 *>(dst + p) = r[i];
+                }
+                if(a.swap_out) r[i] = swap_group(r[i]);
+            }
+        }
+        // the next step's rows are requested now, so that they travel while this step is exchanged and written out
+        const int y0_next = first_row(it + 1);
+        const bool inside_next = it + 1 < n_it && x0 < W && y0_next >= 0 && y0_next + 8 <= H;
+        if(inside_next) fetch(y0_next);
+        if(inside) {
+            const int pc = 8 * it + (r90 ? 7 - by : by);   // chunk position inside the panel row
+#pragma unroll
+            for(int j = 0; j < 8; j++) {
+                uint32_t o[4];
+#pragma unroll
+                for(int m = 0; m < 4; m++) {
+                    auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
+                    const uint32_t lo = r90 ? word(r[7 - 2 * m]) : word(r[2 * m]);
+                    const uint32_t hi = r90 ? word(r[6 - 2 * m]) : word(r[2 * m + 1]);
+                    o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                }
+                const int xl = bx * 8 + j;
+                const int R = r90 ? x0 + j : W - 1 - (x0 + j);
+                const uint32_t ac = (uint32_t)R * (uint32_t)hc + (uint32_t)pc;   // absolute chunk index in the panel image
+                ring[wave][xl * 16 + ((ac ^ (uint32_t)bx) & 15u)] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        wave_lds_fence();
+        {
+            const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+            for(int k = 0; k < 8; k++) {
+                const int xl = k * 8 + rr;
+                const int X = sx * TILE + xl;
+                if(X >= W) continue;
+                const int R = r90 ? X : W - 1 - X;
+                const uint32_t S = (uint32_t)R * (uint32_t)hc;                    // first chunk of this panel row
+                const uint32_t e_prev = S + (uint32_t)min(8 * it, hc);
+                const uint32_t e_now = S + (uint32_t)min(8 * (it + 1), hc);
+                const uint32_t sw_x = (uint32_t)(xl >> 3);                        // the writer's bx for this row
+                const uint32_t lc = e_now >> 3;                                   // lines that end at or before e_now
+                if(8u * lc > e_prev && 8u * lc >= S + 8u) {                       // a whole line of this row just completed
+                    const uint32_t ac = 8u * (lc - 1u) + (uint32_t)c;
+                    store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
+                }
+                if(it == 0 && (S & 7u)) {                                         // head: the row starts inside a line
+                    const uint32_t ac = (S & ~7u) + (uint32_t)c;
+                    if(ac >= S && ac < e_now && ac < ((S + 7u) & ~7u))
+                        store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
+                }
+                if(it == n_it - 1 && (e_now & 7u)) {                              // tail: the row ends inside a line
+                    const uint32_t ac = (e_now & ~7u) + (uint32_t)c;
+                    if(ac < e_now && ac >= S && (e_now & ~7u) >= ((S + 7u) & ~7u))
+                        store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
+                }
+            }
+        }
+        wave_lds_fence();
+        y0 = y0_next;
+        inside = inside_next;
     }
 }
 
