@@ -1,0 +1,70 @@
+"""GPU parity for the colour-conversion, split, fill, copy, synthetic-data and checksum entry points."""
+import numpy as np
+import pytest
+import torch
+
+from util import to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_color_from_rgb888_all_inputs(gpu, oracle, swap):
+    allhex = np.arange(1 << 24, dtype=np.uint32)
+    got = to_np(gpu.color_from_rgb888(to_dev(allhex), swap), np.uint16)
+    exp = np.empty(1 << 24, np.uint16)
+    oracle.lib().lvref_color_hex_n(oracle._p(allhex), oracle._p(exp), 1 << 24, swap)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_color_to32_all_inputs(gpu, oracle, swap):
+    all16 = np.arange(1 << 16, dtype=np.uint16)
+    got = to_np(gpu.color_to32(to_dev(all16), swap), np.uint32)
+    exp = np.empty(1 << 16, np.uint32)
+    oracle.lib().lvref_color_to32_n(oracle._p(all16), oracle._p(exp), 1 << 16, swap)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_image_split(gpu, oracle, swap, fmt):
+    rng = np.random.default_rng(fmt)
+    n = 100003
+    src = rng.integers(0, 256, n * 3, dtype=np.uint8) if fmt == 4 else rng.integers(0, 1 << 32, n, dtype=np.uint32)
+    c, a = gpu.image_split(to_dev(src), fmt, swap)
+    ec, ea = oracle.image_split(src, fmt, swap)
+    assert np.array_equal(to_np(c, np.uint16), ec) and np.array_equal(a.cpu().numpy(), ea)
+
+
+def test_color_fill_and_buffer_copy(gpu):
+    buf = torch.zeros(12345, dtype=torch.int16, device="cuda")
+    gpu.color_fill(buf, 0xA5C3)
+    assert bool((buf.view(torch.int16) == np.int16(np.uint16(0xA5C3).view(np.int16))).all())
+    rng = np.random.default_rng(1)
+    N = 3
+    src = rng.integers(0, 65536, (N, 20, 33), dtype=np.uint16)
+    dst = rng.integers(0, 65536, (N, 40, 50), dtype=np.uint16)
+    d = to_dev(dst)
+    # lv_draw_sw_buffer_copy: width and row count come from dest_area, the source origin from src_area
+    gpu.buffer_copy(d, (5, 7, 24, 18), to_dev(src), (3, 2, 22, 13))
+    exp = dst.copy()
+    exp[:, 7:19, 5:25] = src[:, 2:14, 3:23]
+    assert np.array_equal(to_np(d, np.uint16), exp)
+
+
+def test_synth_and_checksum_match_cpu_definition(gpu, oracle):
+    for kind, dt in ((gpu.SYNTH_U16, np.uint16), (gpu.SYNTH_MASK_UI, np.uint8), (gpu.SYNTH_MASK_UNI, np.uint8),
+                     (gpu.SYNTH_ARGB_UI, np.uint32), (gpu.SYNTH_ARGB_UNI, np.uint32)):
+        g = gpu.synth(kind, 0x5EED0001, 12345678901, (70001,))
+        h = oracle.synth(kind, 0x5EED0001, 12345678901, 70001)
+        assert np.array_equal(to_np(g, dt), h)
+        assert gpu.checksum(g, 777) == oracle.checksum(h, 777)
+    m = oracle.synth(oracle.SYNTH_MASK_UI, 3, 0, 300000)
+    assert abs((m == 0).mean() - 1 / 3) < 0.01 and abs((m == 255).mean() - 1 / 3) < 0.01
+    # shards of one stream concatenate to the stream (what makes any frame partition reproducible)
+    a = gpu.synth(gpu.SYNTH_U16, 5, 0, (1000,))
+    b = gpu.synth(gpu.SYNTH_U16, 5, 1000, (500,))
+    ab = gpu.synth(gpu.SYNTH_U16, 5, 0, (1500,))
+    assert torch.equal(torch.cat([a, b]), ab)
+    assert (gpu.checksum(a, 0) + gpu.checksum(b, 1000)) & 0xFFFFFFFFFFFFFFFF == gpu.checksum(ab, 0)

@@ -264,12 +264,24 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         abort();
     }
 
-    // rotate the whole area on the device
+    // rotate the whole area on the device (staging buffers are kept between calls and grown on demand)
     const size_t px = (size_t)W * H;
-    void *d_in = nullptr, *d_out = nullptr;
-    HIP_OR_DIE(hipMalloc(&d_in, px * 2));
-    HIP_OR_DIE(hipMalloc(&d_out, px * 2));
-    uint16_t * panel = static_cast<uint16_t *>(malloc(px * 2));
+    static thread_local struct {
+        void *d_in = nullptr, *d_out = nullptr;
+        uint16_t * panel = nullptr;
+        size_t cap = 0;
+    } stg;
+    if(px > stg.cap) {
+        if(stg.d_in) HIP_OR_DIE(hipFree(stg.d_in));
+        if(stg.d_out) HIP_OR_DIE(hipFree(stg.d_out));
+        if(stg.panel) HIP_OR_DIE(hipHostFree(stg.panel));
+        HIP_OR_DIE(hipMalloc(&stg.d_in, px * 2));
+        HIP_OR_DIE(hipMalloc(&stg.d_out, px * 2));
+        HIP_OR_DIE(hipHostMalloc(reinterpret_cast<void **>(&stg.panel), px * 2, hipHostMallocDefault));
+        stg.cap = px;
+    }
+    void *d_in = stg.d_in, *d_out = stg.d_out;
+    uint16_t * panel = stg.panel;
     HIP_OR_DIE(hipMemcpy(d_in, color_p, px * 2, hipMemcpyHostToDevice));
     lvgpu_flush_batch_t f;
     memset(&f, 0, sizeof(f));
@@ -287,8 +299,6 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         abort();
     }
     HIP_OR_DIE(hipMemcpy(panel, d_out, px * 2, hipMemcpyDeviceToHost));
-    HIP_OR_DIE(hipFree(d_in));
-    HIP_OR_DIE(hipFree(d_out));
 
     // Hand the panel image to the sink in the reference's transport chunks (src/lv_port.c:466-566): same
     // rectangles, same order.  Each chunk is a contiguous slice of the rotated image.
@@ -339,7 +349,6 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         }
         cfg->draw_bitmap(cfg->user, xd0, yd0, xd1 + 1, yd1 + 1, panel + (size_t)done * line);
     }
-    free(panel);
     g_flush_gpu++;
     flush_ready(drv);  // :571
 }
