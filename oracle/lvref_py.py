@@ -231,7 +231,7 @@ def ref(swap=1):
         L.ref_disp_drv_bits.restype = C.c_uint32
         L.ref_disp_drv_bits.argtypes = [C.c_char_p]
         L.ref_scene_display.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                        C.c_int]
+                                        C.c_int, C.c_int]
         L.ref_scene_fb.restype = C.c_void_p
         L.ref_scene_draw_buf.restype = C.c_void_p
         L.ref_scene_drv.restype = C.c_void_p

@@ -341,13 +341,17 @@ static lv_color_t * g_buf1;
 static lv_color_t * g_fb1; /* captured by capture_flush */
 static int g_fb_w, g_fb_h;
 static int g_flush_calls;
+static int g_px_bytes = 2; /* 3 when the scene display has screen_transp (ARGB8565 draw buffer) */
 
 static void capture_flush(lv_disp_drv_t * drv, const lv_area_t * a, lv_color_t * p)
 {
     int w = a->x2 - a->x1 + 1;
+    const uint8_t * src = (const uint8_t *)p;
+    uint8_t * fb = (uint8_t *)g_fb1;
     for(int y = a->y1; y <= a->y2; y++) {
         if(y < 0 || y >= g_fb_h) continue;
-        memcpy(g_fb1 + (size_t)y * g_fb_w + a->x1, p + (size_t)(y - a->y1) * w, (size_t)w * sizeof(lv_color_t));
+        memcpy(fb + ((size_t)y * g_fb_w + a->x1) * g_px_bytes, src + (size_t)(y - a->y1) * w * g_px_bytes,
+               (size_t)w * g_px_bytes);
     }
     g_flush_calls++;
     lv_disp_flush_ready(drv);
@@ -355,8 +359,10 @@ static void capture_flush(lv_disp_drv_t * drv, const lv_area_t * a, lv_color_t *
 
 /* Register the scene display.  init/deinit/size == NULL/0 keeps LVGL's software context; flush == NULL keeps the
  * capturing flush above.  full_refresh as in the port (src/lv_port.c:242). */
+/* flags: bit 0 = anti-aliasing off (masks are thresholded, lv_draw_sw_blend.c:150-156), bit 1 = screen_transp
+ * (ARGB8565 draw buffer, 3 bytes per pixel) */
 REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * deinit, size_t ctx_size, void * flush,
-                              void * user_data, int full_refresh)
+                              void * user_data, int full_refresh, int flags)
 {
     if(!g_inited) {
         lv_init();
@@ -370,8 +376,9 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
     }
     g_fb_w = hor_res;
     g_fb_h = ver_res;
-    g_buf1 = calloc((size_t)hor_res * ver_res, sizeof(lv_color_t));
-    g_fb1 = calloc((size_t)hor_res * ver_res, sizeof(lv_color_t));
+    g_px_bytes = (flags & 2) ? LV_IMG_PX_SIZE_ALPHA_BYTE : (int)sizeof(lv_color_t);
+    g_buf1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
+    g_fb1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
     g_flush_calls = 0;
     lv_disp_draw_buf_init(&g_dbuf1, g_buf1, NULL, (uint32_t)hor_res * ver_res);
     lv_disp_drv_init(&g_drv1);
@@ -381,6 +388,8 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
     g_drv1.full_refresh = full_refresh ? 1 : 0;
     g_drv1.flush_cb = flush ? (flush_fn)flush : capture_flush;
     g_drv1.user_data = user_data;
+    if(flags & 1) g_drv1.antialiasing = 0;
+    if(flags & 2) g_drv1.screen_transp = 1;
     if(init) {
         g_drv1.draw_ctx_init = (ctx_init_fn)init;
         g_drv1.draw_ctx_deinit = (ctx_init_fn)deinit;
@@ -399,6 +408,10 @@ REF_API void * ref_scene_fb(void)
 REF_API void * ref_scene_draw_buf(void)
 {
     return g_buf1;
+}
+REF_API int ref_scene_px_bytes(void)
+{
+    return g_px_bytes;
 }
 REF_API int ref_scene_flush_calls(void)
 {
@@ -450,7 +463,8 @@ REF_API int ref_scene_build(int id)
     lv_obj_t * scr = lv_disp_get_scr_act(g_disp1);
     lv_obj_clean(scr);
     lv_obj_set_style_bg_color(scr, lv_color_hex(0x203040), 0);
-    lv_obj_set_style_bg_opa(scr, LV_OPA_COVER, 0);
+    lv_obj_set_style_bg_opa(scr, g_drv1.screen_transp ? LV_OPA_60 : LV_OPA_COVER, 0);
+    if(g_drv1.screen_transp) lv_disp_set_bg_opa(g_disp1, LV_OPA_TRANSP);
     int W = g_fb_w, H = g_fb_h;
 
     if(id == 0 || id == 2) {

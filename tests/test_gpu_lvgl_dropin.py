@@ -38,31 +38,34 @@ def world(request, gpu, oracle):
     L.lvgpu_lvgl_bind(_addr(R.lv_draw_sw_init_ctx), _addr(R.lv_draw_sw_blend_basic), _addr(R.lv_disp_flush_ready))
     L.lvgpu_lvgl_set_color_16_swap(swap)
     yield swap, R, L
-    R.ref_scene_display(16, 16, None, None, 0, None, None, 1)  # drop the GPU context before the library goes away
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)  # drop the GPU context before the library goes away
     L.lvgpu_lvgl_bind(None, None, None)
 
 
 def _fb(R, w, h):
+    if R.ref_scene_px_bytes() == 3:
+        return np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint8)), shape=(h * w * 3,)).copy()
     return np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint16)), shape=(h * w,)).copy()
 
 
-def _render_sw(R, w, h, scene):
-    assert R.ref_scene_display(w, h, None, None, 0, None, None, 1) == 0
+def _render_sw(R, w, h, scene, flags=0):
+    assert R.ref_scene_display(w, h, None, None, 0, None, None, 1, flags) == 0
     R.ref_scene_build(scene)
     R.ref_scene_refresh()
     return _fb(R, w, h)
 
 
 @pytest.mark.parametrize("scene", [0, 1, 2])
-@pytest.mark.parametrize("res", [(320, 480), (480, 320)])
-def test_widget_scene_through_gpu_blend(world, scene, res):
+@pytest.mark.parametrize("res,flags", [((320, 480), 0), ((480, 320), 0), ((320, 480), 1), ((320, 240), 2), ((200, 96), 3)])
+def test_widget_scene_through_gpu_blend(world, scene, res, flags):
+    """flags bit 0: anti-aliasing off (mask thresholding); bit 1: transparent screen (ARGB8565 draw buffer)."""
     swap, R, L = world
     w, h = res
-    sw = _render_sw(R, w, h, scene)
+    sw = _render_sw(R, w, h, scene, flags)
     assert len(np.unique(sw)) > 20, "the scene should not be trivial"
     L.lvgpu_lvgl_reset_stats()
     assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit),
-                               L.lvgpu_draw_ctx_size(), None, None, 1) == 0
+                               L.lvgpu_draw_ctx_size(), None, None, 1, flags) == 0
     R.ref_scene_build(scene)
     R.ref_scene_refresh()
     got = _fb(R, w, h)
@@ -88,7 +91,7 @@ def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot):
     cfg = FlushCfg(rot, w * h // 10, 0, C.cast(cb, C.c_void_p), None, None)
     L.lvgpu_lvgl_reset_stats()
     assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit),
-                               L.lvgpu_draw_ctx_size(), _addr(L.lvgpu_flush_cb), C.addressof(cfg), 1) == 0
+                               L.lvgpu_draw_ctx_size(), _addr(L.lvgpu_flush_cb), C.addressof(cfg), 1, 0) == 0
     R.ref_scene_build(2)
     R.ref_scene_refresh()
     st = Stats()
@@ -102,4 +105,4 @@ def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot):
         assert a[:4] == b[:4]
         assert np.array_equal(a[4], b[4])
     # keep cfg/cb alive until the display is gone
-    R.ref_scene_display(16, 16, None, None, 0, None, None, 1)
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)

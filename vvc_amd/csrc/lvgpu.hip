@@ -87,6 +87,7 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
 
     if(d->opa <= 2) return R_NOOP;                                            // :98  LV_OPA_MIN
     if(!intersect(area, d->blend_area, d->clip_area)) return R_NOOP;          // :101
+    if((int64_t)aw(area) * ah(area) > 0x7FFFFFFFll) return fail(LVGPU_ERR_ARG, "area larger than 2^31 pixels");
     // The reference trusts clip_area to lie inside buf_area; a GPU write outside the buffer is not acceptable.
     if(area.x1 < d->buf_area.x1 || area.y1 < d->buf_area.y1 || area.x2 > d->buf_area.x2 || area.y2 > d->buf_area.y2)
         return fail(LVGPU_ERR_ARG, "clip_area reaches outside buf_area");
