@@ -26,7 +26,7 @@ from vvc_amd import lvgpu, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 SEED_DST, SEED_SRC, SEED_MASK = 0x5EED0001, 0x5EED0002, 0x5EED0003
-BYTES_PER_PX = {"blend_flush": 10, "blend": 8, "rotate": 4}
+BYTES_PER_PX = {"blend_flush": 10, "blend": 8, "rotate": 4, "blend_rgb565a8": 7, "blend_flush_rgb565a8": 9}
 
 
 def parse():
@@ -138,12 +138,16 @@ def main():
     ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap)
     area = (0, 0, W - 1, H - 1)
     dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
+    if args.workload.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
+        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
+        a8 = lvgpu.synth(lvgpu.SYNTH_MASK_UI if args.mask == "ui" else lvgpu.SYNTH_MASK_UNI, SEED_MASK, first, (n, H, W))
+        dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
     swap_bytes = 0 if args.swap else 1
 
     def step(stream=None):
-        if args.workload == "blend_flush":
+        if args.workload.startswith("blend_flush"):
             lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
-        elif args.workload == "blend":
+        elif args.workload.startswith("blend"):
             lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
         else:
             lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out, stream=stream)
@@ -153,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     kernel = lvgpu.last_kernel()
     d_first = dst[:4].cpu().numpy().view("uint16").reshape(-1).copy()
-    o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy() if args.workload != "blend" else None
+    o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy() if "flush" in args.workload else None
     for _ in range(max(0, args.warmup - 1)):
         step()
 
@@ -203,7 +207,7 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {
-                "workload": "%s: ARGB8888 over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
+                "workload": "%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
                             "rotation %d, %d frames per GPU" % (args.workload, args.mask, args.swap, W, H, rot * 90, n),
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
             },
@@ -216,7 +220,7 @@ def main():
         }
         if eighth is not None:
             res["eighth_gpu"] = eighth
-        if world == 1 and not args.no_cpu_baseline and args.workload != "rotate":
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("blend_flush", "blend"):
             res["cpu_baseline"] = cpu_baseline(args, W, H, d_first, o_first)
         print(json.dumps(res), flush=True)
     if dist is not None:
