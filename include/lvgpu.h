@@ -177,6 +177,27 @@ typedef struct {
 
 int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * dsc, void * stream);
 
+/*
+ * Display list: n_items blend descriptors applied in order to the same batch of draw buffers, as one launch.
+ * This is the batched form of the call sequence LVGL's producers issue for a scene -- one lv_draw_sw_blend per
+ * object part or per row (libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:118-330 draw_bg, lv_draw_sw_letter.c:246-398
+ * draw_letter_normal, lv_draw_sw_line.c, lv_draw_sw_arc.c, lv_draw_sw_img.c:137-195) -- recorded once and replayed
+ * over thousands of buffers.  Result == lvgpu_blend_batch(&items[0]), lvgpu_blend_batch(&items[1]), ... in order.
+ * Every item must name the same dst, dst_frame_stride, buf_area, n_frames, color_16_swap and dst_argb8565; clip
+ * areas, sources, masks, colours, opacities and blend modes are per item.  src/mask buffers must not overlap dst.
+ * The draw buffers are read once and written once per list (tiles of the buffer stay on chip while the tile's items
+ * are applied), except that an item which needs a whole-area pre-pass (a translucent unmasked fill whose result on
+ * black depends on scan order, lv_draw_sw_blend.c:262-283) or a shape the tile kernel does not take (width not a
+ * multiple of 8 pixels, unaligned dst, ARGB8565 dst) is run through the lvgpu_blend_batch path in its place in the
+ * order.  items is host memory and may be released when the call returns.
+ */
+int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream);
+
+/* The same followed by the flush of the whole buffer (as lvgpu_blend_flush_batch): panel images go to out.  The
+ * geometry (dst, buf_area, n_frames ...) is taken from geom, whose other fields are ignored; n_items may be 0. */
+int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items,
+                                 void * out, int64_t out_frame_stride, int32_t rotation, int32_t swap_bytes, void * stream);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Colour conversion (libraries/lvgl/src/misc/lv_color.h)                                                       */
 /* ------------------------------------------------------------------------------------------------------------ */

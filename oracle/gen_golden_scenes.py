@@ -1,0 +1,45 @@
+"""TEST INFRASTRUCTURE.  Golden display lists: the real LVGL (oracle/_ref, built from the reference's sources) renders
+the widget scenes of oracle/ref_harness.c while a wrapped draw context records every blend descriptor its producers
+issue; the descriptors (inputs) and LVGL's frame buffer (expected output) are stored as
+tests/golden/scene<id>_f<flags>_swap<s>.npz.  Run here, where /root/reference exists:  python -m oracle.gen_golden_scenes
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import lvref_py as O  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+W, H = 480, 320
+
+
+def pack(fb, items):
+    n = len(items)
+    meta = np.zeros((n, 9), np.int32)  # x1 y1 x2 y2 color opa blend_mode has_src has_mask
+    srcs, masks = [], []
+    for i, it in enumerate(items):
+        meta[i] = list(it["area"]) + [it["color"], it["opa"], it["blend_mode"], it["src"] is not None, it["mask"] is not None]
+        if it["src"] is not None:
+            srcs.append(it["src"].ravel())
+        if it["mask"] is not None:
+            masks.append(it["mask"].ravel())
+    return dict(fb=fb, meta=meta, src=np.concatenate(srcs) if srcs else np.zeros(0, np.uint16),
+                mask=np.concatenate(masks) if masks else np.zeros(0, np.uint8))
+
+
+def main():
+    for swap in (1, 0):
+        L = O.ref(swap)
+        assert L is not None, "oracle/_ref is not built (make -C oracle ref)"
+        for scene, flags in ((0, 0), (1, 0), (2, 0), (2, 1)):
+            fb, items = O.recorded_scene(L, W, H, scene, flags)
+            path = os.path.join(GOLD, "scene%d_f%d_swap%d.npz" % (scene, flags, swap))
+            np.savez_compressed(path, **pack(fb, items))
+            print(path, len(items), "descriptors", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

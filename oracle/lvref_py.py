@@ -197,6 +197,12 @@ def argb_blend_flush_batch(dst, src, out, width, height, n_frames, rotation, swa
 _ref = {}
 
 
+class RecItem(C.Structure):
+    """ref_rec_t of oracle/ref_harness.c"""
+    _fields_ = [("area", C.c_int16 * 4), ("src", C.POINTER(C.c_uint16)), ("mask", C.POINTER(C.c_uint8)),
+                ("color", C.c_uint16), ("opa", C.c_uint8), ("blend_mode", C.c_uint8)]
+
+
 def ref_available(swap=1):
     return os.path.exists(os.path.join(_HERE, "_ref", "liblvgl_swap%d.so" % swap))
 
@@ -236,10 +242,38 @@ def ref(swap=1):
         L.ref_scene_draw_buf.restype = C.c_void_p
         L.ref_scene_drv.restype = C.c_void_p
         L.ref_scene_build.argtypes = [C.c_int]
+        if hasattr(L, "ref_record_items"):
+            L.ref_record_items.restype = C.POINTER(RecItem)
+            L.ref_record_ctx_size.restype = C.c_size_t
         assert L.ref_color_16_swap() == swap
         L.ref_init(480, 480)
         _ref[swap] = L
     return _ref[swap]
+
+
+def recorded_scene(L, w, h, scene, flags=0):
+    """Render widget scene `scene` with the real LVGL while recording every blend descriptor its producers issue.
+    Returns (frame buffer as LVGL drew it [h, w] uint16, list of dicts area/src/mask/color/opa/blend_mode)."""
+    vp = lambda f: C.cast(f, C.c_void_p)
+    L.ref_record_reset()
+    assert L.ref_scene_display(w, h, vp(L.ref_record_ctx_init), vp(L.ref_record_ctx_deinit), L.ref_record_ctx_size(),
+                               None, None, 1, flags) == 0
+    L.ref_scene_build(scene)
+    L.ref_record_reset()
+    L.ref_scene_refresh()
+    fb = np.ctypeslib.as_array(C.cast(L.ref_scene_fb(), C.POINTER(C.c_uint16)), shape=(h, w)).copy()
+    items = []
+    rec = L.ref_record_items()
+    for i in range(L.ref_record_count()):
+        r = rec[i]
+        x1, y1, x2, y2 = r.area
+        n = (x2 - x1 + 1, ) and ((y2 - y1 + 1), (x2 - x1 + 1))
+        src = np.ctypeslib.as_array(r.src, shape=n).copy() if r.src else None
+        mask = np.ctypeslib.as_array(r.mask, shape=n).copy() if r.mask else None
+        items.append(dict(area=(x1, y1, x2, y2), src=src, mask=mask, color=r.color, opa=r.opa, blend_mode=r.blend_mode))
+    L.ref_record_reset()
+    L.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+    return fb, items
 
 
 def _area16(a):

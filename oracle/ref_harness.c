@@ -552,3 +552,91 @@ REF_API void ref_scene_refresh(void)
 {
     lv_refr_now(g_disp1);
 }
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* Recorder: a draw context that is LVGL's software context with ->blend wrapped, so that every descriptor the    */
+/* producers issue for a scene (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:95-106 hands them to ctx->blend) is  */
+/* kept, already clipped the way lv_draw_sw_blend_basic clips it (:108-166), with private copies of the source    */
+/* and mask rectangles.  The drawing itself still happens in LVGL's own blend.                                    */
+/* ------------------------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    int16_t area[4];  /* blend_area intersected with the clip area */
+    uint16_t * src;   /* w*h pixels or NULL (fill) */
+    uint8_t * mask;   /* w*h bytes or NULL */
+    uint16_t color;
+    uint8_t opa;
+    uint8_t blend_mode;
+} ref_rec_t;
+
+static ref_rec_t * g_rec;
+static int g_rec_n, g_rec_cap;
+static void (*g_rec_orig)(lv_draw_ctx_t *, const lv_draw_sw_blend_dsc_t *);
+
+static void rec_blend(lv_draw_ctx_t * ctx, const lv_draw_sw_blend_dsc_t * dsc)
+{
+    g_rec_orig(ctx, dsc); /* first: with anti-aliasing off it thresholds the mask in place, and that is what counts */
+    const lv_opa_t * mask = dsc->mask_buf;
+    if(mask && dsc->mask_res == LV_DRAW_MASK_RES_TRANSP) return;
+    if(dsc->mask_res == LV_DRAW_MASK_RES_FULL_COVER) mask = NULL;
+    lv_area_t a;
+    if(!_lv_area_intersect(&a, dsc->blend_area, ctx->clip_area)) return;
+    int w = lv_area_get_width(&a), h = lv_area_get_height(&a);
+    if(g_rec_n == g_rec_cap) {
+        g_rec_cap = g_rec_cap ? g_rec_cap * 2 : 256;
+        g_rec = realloc(g_rec, (size_t)g_rec_cap * sizeof(ref_rec_t));
+    }
+    ref_rec_t * r = &g_rec[g_rec_n++];
+    memset(r, 0, sizeof(*r));
+    r->area[0] = a.x1;
+    r->area[1] = a.y1;
+    r->area[2] = a.x2;
+    r->area[3] = a.y2;
+    r->color = dsc->color.full;
+    r->opa = dsc->opa;
+    r->blend_mode = (uint8_t)dsc->blend_mode;
+    if(dsc->src_buf) {
+        int stride = lv_area_get_width(dsc->blend_area);
+        const lv_color_t * s = dsc->src_buf + (size_t)stride * (a.y1 - dsc->blend_area->y1) + (a.x1 - dsc->blend_area->x1);
+        r->src = malloc((size_t)w * h * 2);
+        for(int y = 0; y < h; y++) memcpy(r->src + (size_t)y * w, s + (size_t)y * stride, (size_t)w * 2);
+    }
+    if(mask) {
+        int stride = lv_area_get_width(dsc->mask_area);
+        const lv_opa_t * m = mask + (size_t)stride * (a.y1 - dsc->mask_area->y1) + (a.x1 - dsc->mask_area->x1);
+        r->mask = malloc((size_t)w * h);
+        for(int y = 0; y < h; y++) memcpy(r->mask + (size_t)y * w, m + (size_t)y * stride, (size_t)w);
+    }
+}
+
+REF_API void ref_record_ctx_init(lv_disp_drv_t * drv, lv_draw_ctx_t * ctx)
+{
+    lv_draw_sw_init_ctx(drv, ctx);
+    lv_draw_sw_ctx_t * sw = (lv_draw_sw_ctx_t *)ctx;
+    g_rec_orig = sw->blend;
+    sw->blend = rec_blend;
+}
+REF_API void ref_record_ctx_deinit(lv_disp_drv_t * drv, lv_draw_ctx_t * ctx)
+{
+    lv_draw_sw_deinit_ctx(drv, ctx);
+}
+REF_API size_t ref_record_ctx_size(void)
+{
+    return sizeof(lv_draw_sw_ctx_t);
+}
+REF_API void ref_record_reset(void)
+{
+    for(int i = 0; i < g_rec_n; i++) {
+        free(g_rec[i].src);
+        free(g_rec[i].mask);
+    }
+    g_rec_n = 0;
+}
+REF_API int ref_record_count(void)
+{
+    return g_rec_n;
+}
+REF_API const ref_rec_t * ref_record_items(void)
+{
+    return g_rec;
+}

@@ -26,3 +26,21 @@ def rand_mask(rng, shape):
 
 
 OPAS = [0, 2, 3, 4, 100, 127, 128, 250, 251, 252, 253, 254, 255]
+
+
+def load_scene(path):
+    """A golden display list (oracle/gen_golden_scenes.py): LVGL's frame buffer and the recorded descriptors."""
+    z = np.load(path)
+    fb, meta, src, mask = z["fb"], z["meta"], z["src"], z["mask"]
+    items, so, mo = [], 0, 0
+    for x1, y1, x2, y2, color, opa, mode, has_src, has_mask in meta.tolist():
+        w, h = x2 - x1 + 1, y2 - y1 + 1
+        it = dict(area=(x1, y1, x2, y2), color=color, opa=opa, blend_mode=mode, src=None, mask=None)
+        if has_src:
+            it["src"] = src[so:so + w * h].reshape(h, w)
+            so += w * h
+        if has_mask:
+            it["mask"] = mask[mo:mo + w * h].reshape(h, w)
+            mo += w * h
+        items.append(it)
+    return fb, items

@@ -101,6 +101,9 @@ def lib():
         "lvgpu_blend_batch": (C.c_int, [C.POINTER(BlendBatch), vp]),
         "lvgpu_flush_rotate_batch": (C.c_int, [C.POINTER(FlushBatch), vp]),
         "lvgpu_blend_flush_batch": (C.c_int, [C.POINTER(BlendFlushBatch), vp]),
+        "lvgpu_blend_list_batch": (C.c_int, [C.POINTER(BlendBatch), C.c_int32, vp]),
+        "lvgpu_blend_list_flush_batch": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, vp, C.c_int64,
+                                                   C.c_int32, C.c_int32, vp]),
         "lvgpu_color_from_rgb888": (C.c_int, [vp, vp, sz, C.c_int, vp]),
         "lvgpu_color_to32": (C.c_int, [vp, vp, sz, C.c_int, vp]),
         "lvgpu_image_split": (C.c_int, [vp, C.c_int, vp, vp, sz, C.c_int, vp]),

@@ -7,9 +7,11 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/lvgpu.h"
 #include "lvgpu_kernels.hpp"
+#include "lvgpu_list.hpp"
 
 using namespace lvgpu;
 
@@ -357,6 +359,213 @@ inline dim3 stream_grid(size_t n)
     return dim3((uint32_t)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// display lists
+// ---------------------------------------------------------------------------------------------------------------
+bool needs_scan_order(const BlendArgs & a)
+{
+    if(a.opa_mode != OM_FILL_PREMULT) return false;
+    const uint32_t pm_black = ((((a.pf.pm_r * 0x8081u) >> 23) & 0x1Fu) << 11) | ((((a.pf.pm_g * 0x8081u) >> 23) & 0x3Fu) << 5) |
+                              (((a.pf.pm_b * 0x8081u) >> 23) & 0x1Fu);
+    return pm_black != a.pf.first_res;
+}
+
+struct ListBuilder {
+    int W, H;
+    uint32_t tiles_x, tiles_y;
+    std::vector<ListItem> items;
+    std::vector<std::vector<uint32_t>> bins;
+    ListBuilder(int w, int h) : W(w), H(h), tiles_x((w + LT - 1) / LT), tiles_y((h + LT - 1) / LT), bins((size_t)tiles_x * tiles_y) {}
+    void add(const BlendArgs & a, int fmt, const lvgpu_area_t & area, const lvgpu_area_t & buf)
+    {
+        ListItem it;
+        memset(&it, 0, sizeof(it));
+        it.src = a.src;
+        it.mask = a.mask;
+        it.src_fs = a.src_fs;
+        it.mask_fs = a.mask_fs;
+        it.src_stride = a.src_stride;
+        it.mask_stride = a.mask_stride;
+        it.x1 = area.x1 - buf.x1;
+        it.y1 = area.y1 - buf.y1;
+        it.x2 = area.x2 - buf.x1;
+        it.y2 = area.y2 - buf.y1;
+        it.color = a.color;
+        it.opa = a.opa;
+        it.opa_mode = a.opa_mode;
+        it.blend_fn = a.blend_fn;
+        it.fmt = fmt;
+        it.swap = a.swap;
+        it.pf = a.pf;
+        const uint32_t id = (uint32_t)items.size();
+        items.push_back(it);
+        for(int ty = it.y1 / LT; ty <= it.y2 / LT; ty++)
+            for(int tx = it.x1 / LT; tx <= it.x2 / LT; tx++) bins[(size_t)ty * tiles_x + tx].push_back(id);
+    }
+    // does item id replace every pixel of tile t without looking at it?
+    bool overwrites(uint32_t t, uint32_t id) const
+    {
+        const ListItem & it = items[id];
+        if(!(it.opa_mode == OM_CONST && it.opa == 255u && it.blend_fn == BF_NORMAL)) return false;
+        if(!(it.fmt == SRC_FILL || it.fmt == SRC_RGB565)) return false;
+        const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
+        const int x1 = tx * LT, y1 = ty * LT, x2 = std::min(x1 + LT, W) - 1, y2 = std::min(y1 + LT, H) - 1;
+        return it.x1 <= x1 && it.y1 <= y1 && it.x2 >= x2 && it.y2 >= y2;
+    }
+    // Items of tile t that can still be seen: everything drawn before the last item that overwrites the whole tile
+    // is dead in this tile.  Returns the position in bins[t] to start from; *ow tells whether that item overwrites.
+    size_t first_live(uint32_t t, bool * ow) const
+    {
+        const std::vector<uint32_t> & b = bins[t];
+        for(size_t i = b.size(); i-- > 0;) {
+            if(overwrites(t, b[i])) {
+                *ow = true;
+                return i;
+            }
+        }
+        *ow = false;
+        return 0;
+    }
+    void clear()
+    {
+        items.clear();
+        for(auto & b : bins) b.clear();
+    }
+};
+
+// Launch the accumulated items.  out != nullptr: also write the panel image of every tile (all tiles are visited).
+int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_frames, int swap, uint16_t * out, long long out_fs,
+                int rot, int swap_out, hipStream_t st)
+{
+    const uint32_t n_tiles = lb.tiles_x * lb.tiles_y;
+    std::vector<uint32_t> bin_start(n_tiles + 1), bin_items, sel;
+    for(uint32_t t = 0; t < n_tiles; t++) {
+        bin_start[t] = (uint32_t)bin_items.size();
+        bool ow = false;
+        const size_t first = lb.first_live(t, &ow);
+        bin_items.insert(bin_items.end(), lb.bins[t].begin() + (long)first, lb.bins[t].end());
+        if(out || !lb.bins[t].empty()) sel.push_back(t | (ow ? 0x80000000u : 0u));
+    }
+    bin_start[n_tiles] = (uint32_t)bin_items.size();
+    if(sel.empty()) return LVGPU_OK;
+    const uint64_t waves = (uint64_t)sel.size() * n_frames;
+    if(waves > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+
+    // one device allocation: items | bin_start | bin_items | sel
+    const size_t b_items = lb.items.size() * sizeof(ListItem), b_start = bin_start.size() * 4, b_bins = bin_items.size() * 4,
+                 b_sel = sel.size() * 4;
+    std::vector<uint8_t> blob(b_items + b_start + b_bins + b_sel);
+    if(b_items) memcpy(blob.data(), lb.items.data(), b_items);
+    memcpy(blob.data() + b_items, bin_start.data(), b_start);
+    if(b_bins) memcpy(blob.data() + b_items + b_start, bin_items.data(), b_bins);
+    memcpy(blob.data() + b_items + b_start + b_bins, sel.data(), b_sel);
+    uint8_t * dev = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob.size(), st));
+    // pageable source: the runtime has consumed the host bytes when this returns
+    HIP_TRY(hipMemcpyAsync(dev, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+
+    ListArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dst = dst;
+    a.dst_fs = dst_fs;
+    a.W = lb.W;
+    a.H = lb.H;
+    a.n_frames = n_frames;
+    a.items = reinterpret_cast<const ListItem *>(dev);
+    a.bin_start = reinterpret_cast<const uint32_t *>(dev + b_items);
+    a.bin_items = reinterpret_cast<const uint32_t *>(dev + b_items + b_start);
+    a.sel = reinterpret_cast<const uint32_t *>(dev + b_items + b_start + b_bins);
+    a.n_sel = (uint32_t)sel.size();
+    a.tiles_x = lb.tiles_x;
+    a.swap = swap;
+    a.out = out;
+    a.out_fs = out_fs;
+    a.rot = rot;
+    a.swap_out = swap_out;
+    hipLaunchKernelGGL(k_blend_list, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(dev, st));
+    lb.clear();
+    return LVGPU_OK;
+}
+
+int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int n_items, bool flush, void * out_v,
+             long long out_fs, int rot, int swap_out, hipStream_t st)
+{
+    g_last_kernel = "";
+    if(n_items < 0) return fail(LVGPU_ERR_ARG, "n_items < 0");
+    if(n_items > 0 && items == nullptr) return fail(LVGPU_ERR_ARG, "items is NULL");
+    if(geom == nullptr) return n_items == 0 && !flush ? LVGPU_OK : fail(LVGPU_ERR_ARG, "descriptor is NULL");
+    if(geom->n_frames < 0) return fail(LVGPU_ERR_ARG, "n_frames < 0");
+    if(flush) {
+        if(out_v == nullptr) return fail(LVGPU_ERR_ARG, "out is NULL");
+        if(rot < LVGPU_ROT_NONE || rot > LVGPU_ROT_270) return fail(LVGPU_ERR_ARG, "bad rotation %d", rot);
+        if(geom->dst_argb8565) return fail(LVGPU_ERR_UNSUPPORTED, "flush of an ARGB8565 buffer (the reference flushes lv_color_t only)");
+        if(aw(geom->buf_area) <= 0 || ah(geom->buf_area) <= 0) return fail(LVGPU_ERR_ARG, "empty buf_area");
+        if((uint64_t)aw(geom->buf_area) * ah(geom->buf_area) > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "frame too large");
+    }
+    if(geom->n_frames == 0) return LVGPU_OK;
+    if(geom->dst == nullptr) return fail(LVGPU_ERR_ARG, "dst is NULL");
+
+    // resolve everything first: nothing is launched when any item is malformed
+    std::vector<BlendArgs> ra((size_t)n_items);
+    std::vector<lvgpu_area_t> areas((size_t)n_items);
+    std::vector<int> res((size_t)n_items);
+    for(int i = 0; i < n_items; i++) {
+        const lvgpu_blend_batch_t & d = items[i];
+        if(d.dst != geom->dst || d.dst_frame_stride != geom->dst_frame_stride || d.n_frames != geom->n_frames ||
+           memcmp(&d.buf_area, &geom->buf_area, sizeof(lvgpu_area_t)) != 0 || (d.color_16_swap != 0) != (geom->color_16_swap != 0) ||
+           (d.dst_argb8565 != 0) != (geom->dst_argb8565 != 0))
+            return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
+        res[i] = resolve_blend(&d, ra[i], areas[i]);
+        if(res[i] < 0) {
+            g_err = "item " + std::to_string(i) + ": " + g_err;
+            return res[i];
+        }
+    }
+    const int W = aw(geom->buf_area), H = ah(geom->buf_area);
+    uint16_t * dst = reinterpret_cast<uint16_t *>(geom->dst);
+    uint16_t * out = reinterpret_cast<uint16_t *>(out_v);
+    const bool argb = geom->dst_argb8565 != 0;
+    const bool tiles_ok = !argb && (W % 8) == 0 && aligned(dst, 16) && (geom->dst_frame_stride % 8) == 0;
+    const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
+    const bool fuse_out = flush && tiles_ok && aligned(out, 16) && (out_fs % 8) == 0 && (!transposing || (H % 8) == 0);
+
+    ListBuilder lb(W, H);
+    int rc;
+    bool used_list = false;
+    for(int i = 0; i < n_items; i++) {
+        if(res[i] != R_WORK) continue;
+        if(tiles_ok && !needs_scan_order(ra[i])) {
+            lb.add(ra[i], items[i].src_format, areas[i], geom->buf_area);
+            continue;
+        }
+        if(!lb.items.empty()) {
+            rc = launch_list(lb, dst, geom->dst_frame_stride, (uint32_t)geom->n_frames, geom->color_16_swap ? 1 : 0, nullptr, 0,
+                             0, 0, st);
+            if(rc != LVGPU_OK) return rc;
+            used_list = true;
+        }
+        rc = launch_blend(ra[i], items[i].src_format, st, argb);
+        if(rc != LVGPU_OK) return rc;
+    }
+    if(fuse_out && !lb.items.empty()) {
+        rc = launch_list(lb, dst, geom->dst_frame_stride, (uint32_t)geom->n_frames, geom->color_16_swap ? 1 : 0, out, out_fs, rot,
+                         swap_out ? 1 : 0, st);
+        if(rc == LVGPU_OK) g_last_kernel = "k_blend_list(fused)";
+        return rc;
+    }
+    if(!lb.items.empty()) {
+        rc = launch_list(lb, dst, geom->dst_frame_stride, (uint32_t)geom->n_frames, geom->color_16_swap ? 1 : 0, nullptr, 0, 0, 0,
+                         st);
+        if(rc != LVGPU_OK) return rc;
+        used_list = true;
+    }
+    if(flush) return launch_rotate(dst, geom->dst_frame_stride, out, out_fs, W, H, rot, swap_out, geom->n_frames, st);
+    if(used_list) g_last_kernel = "k_blend_list";
+    return LVGPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -491,6 +700,17 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     }
     return launch_rotate(reinterpret_cast<const uint16_t *>(b.dst), b.dst_frame_stride, reinterpret_cast<uint16_t *>(d->out),
                          d->out_frame_stride, W, H, d->rotation, d->swap_bytes, b.n_frames, st);
+}
+
+int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream)
+{
+    return run_list(n_items > 0 ? items : nullptr, items, n_items, false, nullptr, 0, 0, 0, (hipStream_t)stream);
+}
+
+int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, void * out,
+                                 int64_t out_frame_stride, int32_t rotation, int32_t swap_bytes, void * stream)
+{
+    return run_list(geom, items, n_items, true, out, out_frame_stride, rotation, swap_bytes, (hipStream_t)stream);
 }
 
 int lvgpu_color_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap, void * stream)

@@ -55,7 +55,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n_blocks)
 // ---------------------------------------------------------------------------------------------------------------
 // one pixel
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t px_core(const BlendArgs & a, uint32_t d, uint32_t fg, uint32_t m,
+template <class A>  // BlendArgs or a display-list item: anything with opa_mode, opa, blend_fn, swap, pf
+__device__ __forceinline__ uint32_t px_core(const A & a, uint32_t d, uint32_t fg, uint32_t m,
                                             uint32_t scan_idx, uint32_t fnb)
 {
     uint32_t o;
@@ -71,6 +72,31 @@ __device__ __forceinline__ uint32_t px_core(const BlendArgs & a, uint32_t d, uin
         case BF_SUBTRACTIVE: fg = px_blend_fn<BF_SUBTRACTIVE>(fg, d, a.swap); break;
         case BF_MULTIPLY: fg = px_blend_fn<BF_MULTIPLY>(fg, d, a.swap); break;
         default: break;
+    }
+    return px_mix(fg, d, o);
+}
+
+// The same with the opacity mode fixed at compile time (OM) and the blend function either known to be the normal
+// one (BLENDED == false) or chosen at run time.  The mode is uniform over a launch or a display-list item; taking
+// the decision out of the per-pixel code removes a handful of scalar branches per pixel.  OM_RUNTIME = decide per pixel.
+// OM_OPAQUE = OM_CONST with opa 255 and the normal blend function: lv_color_mix(fg, bg, 255) is fg whatever bg is
+// (m5 = 32: ((f - b) * 32 >> 5) + b == f in every field), so the destination is not even read.
+constexpr int OM_RUNTIME = -1;
+constexpr int OM_OPAQUE = 5;
+template <int OM, bool BLENDED, class A>
+__device__ __forceinline__ uint32_t px_core_s(const A & a, uint32_t d, uint32_t fg, uint32_t m, uint32_t scan_idx, uint32_t fnb)
+{
+    if(OM == OM_RUNTIME) return px_core(a, d, fg, m, scan_idx, fnb);
+    if(OM == OM_OPAQUE) return fg;
+    if(OM == OM_FILL_PREMULT) return px_fill_premult(a.pf, d, scan_idx, fnb);
+    const uint32_t o = OM == OM_CONST ? a.opa : px_opa<OM>(m, a.opa);
+    if(BLENDED) {
+        switch(a.blend_fn) {
+            case BF_ADDITIVE: fg = px_blend_fn<BF_ADDITIVE>(fg, d, a.swap); break;
+            case BF_SUBTRACTIVE: fg = px_blend_fn<BF_SUBTRACTIVE>(fg, d, a.swap); break;
+            case BF_MULTIPLY: fg = px_blend_fn<BF_MULTIPLY>(fg, d, a.swap); break;
+            default: break;
+        }
     }
     return px_mix(fg, d, o);
 }
@@ -128,10 +154,10 @@ __device__ __forceinline__ void load_src(const void * base, long long px, uint32
 }
 
 // Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
-template <int SRC>
-__device__ __forceinline__ uint4 blend_group(const BlendArgs & a, uint4 d, const uint32_t * sw, uint2 mk,
-                                             uint32_t scan0, uint32_t fnb)
+template <int SRC, int OM, bool BLENDED, class A>
+__device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
+    if(OM == OM_OPAQUE && SRC == SRC_RGB565) return make_uint4(sw[0], sw[1], sw[2], sw[3]);  // same stored format
     uint32_t dw[4] = {d.x, d.y, d.z, d.w};
     if(a.swap) {
 #pragma unroll
@@ -144,7 +170,7 @@ __device__ __forceinline__ uint4 blend_group(const BlendArgs & a, uint4 d, const
         uint32_t fg = a.color;
         uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
         src_px<SRC>(sw, j, a.swap, fg, m);
-        uint32_t r = px_core(a, dn, fg, m, scan0 + (uint32_t)j, fnb);
+        uint32_t r = px_core_s<OM, BLENDED>(a, dn, fg, m, scan0 + (uint32_t)j, fnb);
         if(j & 1) rw[j >> 1] |= r << 16;
         else rw[j >> 1] = r;
     }
@@ -153,6 +179,11 @@ __device__ __forceinline__ uint4 blend_group(const BlendArgs & a, uint4 d, const
         for(int i = 0; i < 4; i++) rw[i] = px_swap16x2(rw[i]);
     }
     return make_uint4(rw[0], rw[1], rw[2], rw[3]);
+}
+template <int SRC, class A>
+__device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
+{
+    return blend_group_s<SRC, OM_RUNTIME, true>(a, d, sw, mk, scan0, fnb);
 }
 
 // The panel image is written once and never read back by these kernels: a non-temporal store keeps it from

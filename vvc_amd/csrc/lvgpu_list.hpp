@@ -1,0 +1,317 @@
+// lvgpu_list.hpp -- display-list kernel: an ordered list of blend descriptors applied to a batch of draw buffers in
+// ONE launch.  LVGL's producers call lv_draw_sw_blend once per object part or even once per row
+// (libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:118-330, lv_draw_sw_letter.c:246-398, lv_draw_sw_line.c,
+// lv_draw_sw_arc.c); a scene is hundreds to thousands of small descriptors.  Launching one kernel per descriptor
+// re-reads and re-writes the draw buffers once per layer and is launch-bound for the small ones.  Here the buffer
+// is cut into 64x64-pixel tiles, the host bins the descriptors by tile, and a wavefront keeps its tile in LDS while
+// it applies the tile's descriptors in list order: the draw buffer is read once and written once per list whatever
+// the depth of the scene, and the result is what the same descriptors give when applied one after the other
+// (pixels are independent within a descriptor and every pixel sees the descriptors in list order).
+#pragma once
+#include "lvgpu_kernels.hpp"
+
+namespace lvgpu {
+
+struct ListItem {
+    const void * src;      // first source pixel of the clipped area in frame 0
+    const uint8_t * mask;  // first mask byte of the clipped area in frame 0, or nullptr
+    long long src_fs;      // source pixels between frames
+    long long mask_fs;     // bytes between frames
+    int src_stride;        // pixels
+    int mask_stride;       // bytes
+    int x1, y1, x2, y2;    // clipped area, pixels relative to the buffer origin, inclusive
+    uint32_t color;        // native fill colour
+    uint32_t opa;
+    int opa_mode;          // OpaMode
+    int blend_fn;          // BlendFn
+    int fmt;               // source format
+    int swap;              // LV_COLOR_16_SWAP
+    PremultFill pf;        // OM_FILL_PREMULT only (lists hold such fills only when black needs no scan-order cache)
+};
+
+struct ListArgs {
+    uint16_t * dst;
+    long long dst_fs;
+    int W, H;                    // buffer size, W % 8 == 0
+    uint32_t n_frames;
+    const ListItem * items;
+    const uint32_t * bin_start;  // per tile: first entry of the tile in bin_items; tiles_x*tiles_y + 1 entries
+    const uint32_t * bin_items;  // item indices, ascending within a tile
+    const uint32_t * sel;        // tiles to process: tile index, bit 31 set = the tile's first item overwrites it whole
+    uint32_t n_sel;
+    uint32_t tiles_x;
+    int swap;
+    uint16_t * out;              // rotated / copied panel image (frame 0) or nullptr
+    long long out_fs;
+    int rot;
+    int swap_out;
+};
+
+constexpr int LT = 64;  // tile edge, pixels
+
+// Position of pixel (row, col) of the tile in the wave's LDS area, in pixels.  Rows are 128 bytes; the 16-byte
+// chunks of a row are XOR-swizzled with the row's 8-row band so that the column gathers of the 90/270-degree output
+// (8 lanes reading the same column of 8 different bands) fall into different banks.
+__device__ __forceinline__ int lt_pos(int row, int col)
+{
+    return row * LT + ((((col >> 3) ^ (row >> 3)) & 7) << 3) + (col & 7);
+}
+
+// Source colour and alpha of one pixel at area-relative (ax, ay).
+template <int SRC>
+__device__ __forceinline__ void list_fetch(const ListItem & it, uint32_t f, int ax, int ay, uint32_t & fg, uint32_t & m)
+{
+    const long long sp = (long long)f * it.src_fs + (long long)ay * it.src_stride + ax;
+    if(SRC == SRC_RGB565) {
+        const uint32_t v = reinterpret_cast<const uint16_t *>(it.src)[sp];
+        fg = it.swap ? px_swap16(v) : v;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(it.src)[sp];
+        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+        m = v >> 24;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const uint8_t * p = reinterpret_cast<const uint8_t *>(it.src) + sp * 3;
+        const uint32_t v = p[0] | (p[1] << 8);
+        fg = it.swap ? px_swap16(v) : v;
+        m = p[2];
+    }
+    if(it.mask) m = it.mask[(long long)f * it.mask_fs + (long long)ay * it.mask_stride + ax];
+}
+
+// The part of an item that falls into the wave's tile, in tile-relative pixels; (ox, oy) turns a tile-relative
+// position into a position relative to the item's clipped area.
+struct ListRegion {
+    int x1, y1, x2, y2;
+    int ox, oy;
+};
+
+// idx / d for idx < 4096, 1 <= d <= 64, exact: (idx + 0.5) / d stays at least 1/128 away from an integer
+__device__ __forceinline__ uint32_t small_div(uint32_t idx, float inv_d)
+{
+    return (uint32_t)(((float)idx + 0.5f) * inv_d);
+}
+
+// Columns [x1, a_end) and [b_start, x2] of the region's rows -- what is left and right of the whole 8-pixel groups,
+// or the whole region when it holds no whole group (a_end = x2 + 1) -- one pixel per lane and step.
+constexpr int LP_UNROLL = 4;
+template <int SRC, int OM, bool BLENDED>
+__device__ __forceinline__ void list_pixels(const ListItem & it, uint16_t * tile, uint32_t f, const ListRegion & r, int a_end,
+                                            int b_start, int lane)
+{
+    const uint32_t wa = (uint32_t)(a_end - r.x1), wb = (uint32_t)(r.x2 + 1 - b_start);
+    const uint32_t rw = wa + wb, n = rw * (uint32_t)(r.y2 - r.y1 + 1);
+    if(n == 0) return;
+    const float inv = 1.0f / (float)rw;
+    for(uint32_t base = (uint32_t)lane; base < n; base += 64 * LP_UNROLL) {
+        uint32_t d[LP_UNROLL], fg[LP_UNROLL], m[LP_UNROLL];
+        int li[LP_UNROLL];
+#pragma unroll
+        for(int u = 0; u < LP_UNROLL; u++) {
+            const uint32_t idx = base + 64u * u;
+            if(idx < n) {
+                const uint32_t ly = small_div(idx, inv), lx = idx - ly * rw;
+                const int col = lx < wa ? r.x1 + (int)lx : b_start + (int)(lx - wa), row = r.y1 + (int)ly;
+                li[u] = lt_pos(row, col);
+                fg[u] = it.color;
+                m[u] = 0;
+                list_fetch<SRC>(it, f, col + r.ox, row + r.oy, fg[u], m[u]);
+                d[u] = OM == OM_OPAQUE ? 0u : tile[li[u]];
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < LP_UNROLL; u++) {
+            if(base + 64u * u < n) {
+                uint32_t dn = it.swap ? px_swap16(d[u]) : d[u];
+                uint32_t res = px_core_s<OM, BLENDED>(it, dn, fg[u], m[u], 0u, 0u);
+                if(it.swap) res = px_swap16(res);
+                tile[li[u]] = (uint16_t)res;
+            }
+        }
+    }
+}
+
+// Group columns g_lo..g_hi-1 (8 pixels each) of the region's rows, one group per lane and step.
+constexpr int LG_UNROLL = 2;
+template <int SRC, int OM, bool BLENDED>
+__device__ __forceinline__ void list_groups(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion & r, int g_lo,
+                                            int g_hi, int lane)
+{
+    const uint32_t ng = (uint32_t)(g_hi - g_lo), n = ng * (uint32_t)(r.y2 - r.y1 + 1);
+    const float inv = 1.0f / (float)ng;
+    for(uint32_t base = (uint32_t)lane; base < n; base += 64 * LG_UNROLL) {
+        uint4 d[LG_UNROLL];
+        uint2 mk[LG_UNROLL];
+        uint32_t sw[LG_UNROLL][SrcWords<SRC>::N];
+        int li[LG_UNROLL];
+#pragma unroll
+        for(int u = 0; u < LG_UNROLL; u++) {
+            const uint32_t idx = base + 64u * u;
+            mk[u] = make_uint2(0, 0);
+            if(idx < n) {
+                const uint32_t ly = small_div(idx, inv), lg = idx - ly * ng;
+                const int row = r.y1 + (int)ly, g = g_lo + (int)lg;
+                li[u] = row * 8 + ((g ^ (row >> 3)) & 7);
+                const int ax = g * 8 + r.ox, ay = row + r.oy;
+                if(SRC != SRC_FILL)
+                    load_src_unaligned<SRC>(it.src, (long long)f * it.src_fs + (long long)ay * it.src_stride + ax, sw[u]);
+                if(it.mask) {
+                    u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(it.mask + (long long)f * it.mask_fs +
+                                                                     (long long)ay * it.mask_stride + ax);
+                    mk[u] = make_uint2(v.x, v.y);
+                }
+                d[u] = OM == OM_OPAQUE ? make_uint4(0, 0, 0, 0) : tile4[li[u]];
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < LG_UNROLL; u++) {
+            if(base + 64u * u < n) tile4[li[u]] = blend_group_s<SRC, OM, BLENDED>(it, d[u], sw[u], mk[u], 0u, 0u);
+        }
+    }
+}
+
+// One item on one tile: whole 8-pixel groups of the tile that lie inside the region go as vectors, the columns left
+// and right of them (and regions narrower than a group) pixel by pixel.
+template <int SRC, int OM, bool BLENDED>
+__device__ __forceinline__ void list_item(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion r, int lane)
+{
+    const int g_lo = (r.x1 + 7) >> 3, g_hi = (r.x2 + 1) >> 3;
+    uint16_t * tile = reinterpret_cast<uint16_t *>(tile4);
+    if(g_hi > g_lo) {
+        list_groups<SRC, OM, BLENDED>(it, tile4, f, r, g_lo, g_hi, lane);
+        list_pixels<SRC, OM, BLENDED>(it, tile, f, r, g_lo * 8, g_hi * 8, lane);
+    }
+    else list_pixels<SRC, OM, BLENDED>(it, tile, f, r, r.x2 + 1, r.x2 + 1, lane);
+}
+
+// Pick the specialisation for the item's (uniform) opacity mode and blend function.  The combinations the host
+// produces are listed; anything else takes the run-time path.
+template <int SRC>
+__device__ __forceinline__ void list_dispatch(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion & r, int lane)
+{
+    constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
+    const bool normal = it.blend_fn == BF_NORMAL;
+    if(normal) {
+        switch(it.opa_mode) {
+            case OM_CONST:
+                if(!own_alpha && it.opa == 255u) return list_item<SRC, OM_OPAQUE, false>(it, tile4, f, r, lane);
+                if(!own_alpha) return list_item<SRC, OM_CONST, false>(it, tile4, f, r, lane);
+                break;
+            case OM_MASK: return list_item<SRC, OM_MASK, false>(it, tile4, f, r, lane);
+            case OM_FILL_MASK_OPA:
+                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_MASK_OPA, false>(it, tile4, f, r, lane);
+                break;
+            case OM_MAP_MASK_OPA:
+                if(SRC != SRC_FILL) return list_item<SRC, OM_MAP_MASK_OPA, false>(it, tile4, f, r, lane);
+                break;
+            case OM_FILL_PREMULT:
+                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_PREMULT, false>(it, tile4, f, r, lane);
+                break;
+            default: break;
+        }
+    }
+    list_item<SRC, OM_RUNTIME, true>(it, tile4, f, r, lane);
+}
+
+__global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
+{
+    __shared__ uint4 lds4[4][LT * LT / 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
+    if(wt >= a.n_sel * a.n_frames) return;  // waves never wait for each other below
+    const uint32_t f = wt / a.n_sel;
+    const uint32_t sel = a.sel[wt - f * a.n_sel];
+    const uint32_t t = sel & 0x7FFFFFFFu;
+    const bool overwrite = (sel >> 31) != 0;
+    const int ty = (int)(t / a.tiles_x), tx = (int)(t - (uint32_t)ty * a.tiles_x);
+    const int W = a.W, H = a.H;
+    uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+    uint4 * tile4 = lds4[wave];
+    uint16_t * tile = reinterpret_cast<uint16_t *>(tile4);
+    const int bx = lane & 7, by = lane >> 3;
+    const int gx = tx * LT + bx * 8;
+    const uint32_t k0 = a.bin_start[t], k1 = a.bin_start[t + 1];
+
+    if(!overwrite && gx < W) {
+#pragma unroll
+        for(int i = 0; i < 8; i++) {
+            const int row = by * 8 + i, y = ty * LT + row;
+            if(y < H) tile4[row * 8 + (bx ^ by)] = *reinterpret_cast<const uint4 *>(dst + (size_t)y * W + gx);
+        }
+    }
+    wave_lds_fence();
+
+    uint32_t next_id = k0 < k1 ? a.bin_items[k0] : 0u;
+    for(uint32_t k = k0; k < k1; k++) {
+        const ListItem & it = a.items[__builtin_amdgcn_readfirstlane(next_id)];
+        if(k + 1 < k1) next_id = a.bin_items[k + 1];  // requested now, needed after this item
+        ListRegion r;
+        r.x1 = max(it.x1, tx * LT) - tx * LT;
+        r.x2 = min(it.x2, tx * LT + LT - 1) - tx * LT;
+        r.y1 = max(it.y1, ty * LT) - ty * LT;
+        r.y2 = min(it.y2, ty * LT + LT - 1) - ty * LT;
+        if(r.x2 < r.x1 || r.y2 < r.y1) continue;
+        r.ox = tx * LT - it.x1;  // tile-relative -> area-relative
+        r.oy = ty * LT - it.y1;
+        switch(it.fmt) {
+            case SRC_FILL: list_dispatch<SRC_FILL>(it, tile4, f, r, lane); break;
+            case SRC_RGB565: list_dispatch<SRC_RGB565>(it, tile4, f, r, lane); break;
+            case SRC_ARGB8888: list_dispatch<SRC_ARGB8888>(it, tile4, f, r, lane); break;
+            case SRC_RGBA8888: list_dispatch<SRC_RGBA8888>(it, tile4, f, r, lane); break;
+            default: list_dispatch<SRC_ARGB8565>(it, tile4, f, r, lane); break;
+        }
+        wave_lds_fence();
+    }
+
+    if(gx < W) {
+        const bool wr_dst = k1 > k0;
+        uint16_t * out = a.out ? a.out + (long long)f * a.out_fs : nullptr;
+        const bool linear_out = out && (a.rot == 0 || a.rot == 2);
+        const size_t area = (size_t)W * H;
+#pragma unroll
+        for(int i = 0; i < 8; i++) {
+            const int row = by * 8 + i, y = ty * LT + row;
+            if(y < H) {
+                uint4 v = tile4[row * 8 + (bx ^ by)];
+                const size_t p = (size_t)y * W + gx;
+                if(wr_dst) *reinterpret_cast<uint4 *>(dst + p) = v;
+                if(linear_out) {
+                    if(a.swap_out) v = swap_group(v);
+                    if(a.rot == 2) store_streaming(out + (area - 8 - p), reverse_group(v));
+                    else store_streaming(out + p, v);
+                }
+            }
+        }
+    }
+    if(a.out && (a.rot == 1 || a.rot == 3)) {  // H % 8 == 0 (checked by the launcher)
+        uint16_t * out = a.out + (long long)f * a.out_fs;
+        const int rr = lane >> 3, c = lane & 7;
+        const int yb = ty * LT + c * 8;
+#pragma unroll
+        for(int k = 0; k < 8; k++) {
+            const int xl = k * 8 + rr;
+            const int X = tx * LT + xl;
+            if(X < W && yb < H) {
+                uint32_t px[8];
+#pragma unroll
+                for(int q = 0; q < 8; q++) px[q] = tile[lt_pos(c * 8 + q, xl)];
+                uint4 v;
+                size_t o;
+                if(a.rot == 1) {
+                    v = make_uint4(px[7] | (px[6] << 16), px[5] | (px[4] << 16), px[3] | (px[2] << 16), px[1] | (px[0] << 16));
+                    o = (size_t)X * H + (size_t)(H - 8 - yb);
+                }
+                else {
+                    v = make_uint4(px[0] | (px[1] << 16), px[2] | (px[3] << 16), px[4] | (px[5] << 16), px[6] | (px[7] << 16));
+                    o = (size_t)(W - 1 - X) * H + (size_t)yb;
+                }
+                if(a.swap_out) v = swap_group(v);
+                store_streaming(out + o, v);
+            }
+        }
+    }
+}
+
+}  // namespace lvgpu

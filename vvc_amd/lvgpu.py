@@ -177,6 +177,43 @@ def blend_flush(ctx, dsc, rotation, swap_bytes=0, out=None, stream=None):
     return out
 
 
+def _fill_list(ctx, dscs, clips):
+    """An array of lvgpu_blend_batch_t for a display list; clips: one clip area per item (LVGL changes the clip
+    area from object to object) or None for ctx.clip_area throughout."""
+    arr = (BlendBatch * max(len(dscs), 1))()
+    saved = ctx.clip_area
+    try:
+        for i, d in enumerate(dscs):
+            if clips is not None:
+                ctx.clip_area = Area.of(clips[i])
+            arr[i] = _fill_batch(ctx, d)
+    finally:
+        ctx.clip_area = saved
+    return arr
+
+
+def blend_list(ctx, dscs, clips=None, stream=None):
+    """The descriptors of a whole scene applied in order to every frame of ctx.buf as one launch; same result as
+    calling lv_draw_sw_blend on each of them in turn."""
+    arr = _fill_list(ctx, dscs, clips)
+    check(_lib.lib().lvgpu_blend_list_batch(arr, len(dscs), _stream(stream)))
+
+
+def blend_list_flush(ctx, dscs, rotation, swap_bytes=0, clips=None, out=None, stream=None):
+    """blend_list followed by the flush of the whole buffer (panel images returned), in the same launch where the
+    shapes allow it."""
+    n, h, w = ctx.buf.shape[:3]
+    if out is None:
+        shape = (n, w, h) if rotation in (LV_DISP_ROT_90, LV_DISP_ROT_270) else (n, h, w)
+        out = torch.empty(shape, dtype=ctx.buf.dtype, device=ctx.buf.device)
+    arr = _fill_list(ctx, dscs, clips)
+    geom = _fill_batch(ctx, BlendDsc(ctx.buf_area))
+    check(_lib.lib().lvgpu_blend_list_flush_batch(C.byref(geom), arr, len(dscs), out.data_ptr(),
+                                                   (out.stride(0) if n > 1 else h * w), rotation, int(swap_bytes),
+                                                   _stream(stream)))
+    return out
+
+
 def color_from_rgb888(xrgb, color_16_swap=1, stream=None):
     """lv_color_hex over a uint32/int32 tensor of 0x00RRGGBB words."""
     out = torch.empty(xrgb.shape, dtype=torch.int16, device=xrgb.device)
