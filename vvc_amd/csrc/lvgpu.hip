@@ -433,32 +433,95 @@ struct ListBuilder {
     }
 };
 
-// Launch the accumulated items.  out != nullptr: also write the panel image of every tile (all tiles are visited).
+// An item's part of a tile with fewer pixels than this is cut into chunks and batched with its neighbours in the
+// list; larger parts are walked by the whole wave on their own.
+constexpr int LIST_BIG_REGION = 512;
+
+uint32_t item_kind(const ListItem & it)
+{
+    const bool own_alpha = it.fmt == SRC_ARGB8888 || it.fmt == SRC_RGBA8888 || it.fmt == SRC_ARGB8565;
+    const bool blended = it.blend_fn != BF_NORMAL;
+    int om = blended ? 7 : it.opa_mode;
+    if(!blended && it.opa_mode == OM_CONST && it.opa == 255u && !own_alpha) om = OM_OPAQUE;
+    return list_kind(it.fmt, om, blended) | (it.mask ? 128u : 0u);
+}
+
+// Turn the bins into per-tile step lists (see ListStep / ListChunk in lvgpu_list.hpp) and launch.
+// out != nullptr: also write the panel image of every tile (all tiles are visited).
 int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_frames, int swap, uint16_t * out, long long out_fs,
                 int rot, int swap_out, hipStream_t st)
 {
     const uint32_t n_tiles = lb.tiles_x * lb.tiles_y;
-    std::vector<uint32_t> bin_start(n_tiles + 1), bin_items, sel;
+    std::vector<uint32_t> bin_start(n_tiles + 1), sel;
+    std::vector<uint4> steps;
+    std::vector<uint2> chunks, full, part;
     for(uint32_t t = 0; t < n_tiles; t++) {
-        bin_start[t] = (uint32_t)bin_items.size();
+        bin_start[t] = (uint32_t)steps.size();
         bool ow = false;
         const size_t first = lb.first_live(t, &ow);
-        bin_items.insert(bin_items.end(), lb.bins[t].begin() + (long)first, lb.bins[t].end());
-        if(out || !lb.bins[t].empty()) sel.push_back(t | (ow ? 0x80000000u : 0u));
+        const int tx0 = (int)(t % lb.tiles_x) * LT, ty0 = (int)(t / lb.tiles_x) * LT;
+        uint32_t kind = 0;
+        uint64_t occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per group column: rows of the tile the current batch touches
+        auto flush = [&]() {
+            if(full.empty() && part.empty()) return;
+            steps.push_back(make_uint4(kind & 0x7Fu, (uint32_t)chunks.size(), (uint32_t)full.size(), (uint32_t)part.size()));
+            chunks.insert(chunks.end(), full.begin(), full.end());
+            chunks.insert(chunks.end(), part.begin(), part.end());
+            full.clear();
+            part.clear();
+            for(auto & o : occ) o = 0;
+        };
+        for(size_t i = first; i < lb.bins[t].size(); i++) {
+            const uint32_t id = lb.bins[t][i];
+            const ListItem & it = lb.items[id];
+            const int x1 = std::max(it.x1, tx0) - tx0, x2 = std::min(it.x2, tx0 + LT - 1) - tx0;
+            const int y1 = std::max(it.y1, ty0) - ty0, y2 = std::min(it.y2, ty0 + LT - 1) - ty0;
+            if(x2 < x1 || y2 < y1) continue;
+            if((x2 - x1 + 1) * (y2 - y1 + 1) >= LIST_BIG_REGION) {
+                flush();
+                steps.push_back(make_uint4(LIST_STEP_ITEM | id, 0, 0, 0));
+                continue;
+            }
+            const uint32_t k = item_kind(it);
+            const uint64_t rows = (y2 - y1 == 63 ? ~0ull : ((1ull << (y2 - y1 + 1)) - 1ull) << y1);
+            bool conflict = false;
+            for(int g = x1 >> 3; g <= (x2 >> 3); g++) conflict = conflict || (occ[g] & rows) != 0;
+            if(k != kind || conflict) flush();
+            kind = k;
+            for(int g = x1 >> 3; g <= (x2 >> 3); g++) {
+                occ[g] |= rows;
+                const int lo = std::max(x1, g * 8) - g * 8, hi = std::min(x2, g * 8 + 7) - g * 8;
+                const uint32_t pxmask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+                for(int y = y1; y <= y2; y++)
+                    (pxmask == 0xFFu ? full : part).push_back(make_uint2(id, (uint32_t)y | ((uint32_t)g << 6) | (pxmask << 9)));
+            }
+        }
+        flush();
+        if(out || steps.size() > bin_start[t]) sel.push_back(t | (ow ? 0x80000000u : 0u));
     }
-    bin_start[n_tiles] = (uint32_t)bin_items.size();
-    if(sel.empty()) return LVGPU_OK;
+    bin_start[n_tiles] = (uint32_t)steps.size();
+    if(sel.empty()) {
+        lb.clear();
+        return LVGPU_OK;
+    }
     const uint64_t waves = (uint64_t)sel.size() * n_frames;
     if(waves > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
 
-    // one device allocation: items | bin_start | bin_items | sel
-    const size_t b_items = lb.items.size() * sizeof(ListItem), b_start = bin_start.size() * 4, b_bins = bin_items.size() * 4,
-                 b_sel = sel.size() * 4;
-    std::vector<uint8_t> blob(b_items + b_start + b_bins + b_sel);
-    if(b_items) memcpy(blob.data(), lb.items.data(), b_items);
-    memcpy(blob.data() + b_items, bin_start.data(), b_start);
-    if(b_bins) memcpy(blob.data() + b_items + b_start, bin_items.data(), b_bins);
-    memcpy(blob.data() + b_items + b_start + b_bins, sel.data(), b_sel);
+    // one device allocation: steps | items | chunks | bin_start | sel   (16-, 8-, 8-, 4-, 4-byte elements)
+    const size_t b_steps = steps.size() * sizeof(uint4), b_items = lb.items.size() * sizeof(ListItem),
+                 b_chunks = chunks.size() * sizeof(uint2), b_start = bin_start.size() * 4, b_sel = sel.size() * 4;
+    static_assert(sizeof(ListItem) % 8 == 0, "chunks must stay 8-byte aligned behind the items");
+    std::vector<uint8_t> blob(b_steps + b_items + b_chunks + b_start + b_sel);
+    uint8_t * w = blob.data();
+    auto put = [&w](const void * p, size_t n) {
+        if(n) memcpy(w, p, n);
+        w += n;
+    };
+    put(steps.data(), b_steps);
+    put(lb.items.data(), b_items);
+    put(chunks.data(), b_chunks);
+    put(bin_start.data(), b_start);
+    put(sel.data(), b_sel);
     uint8_t * dev = nullptr;
     HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob.size(), st));
     // pageable source: the runtime has consumed the host bytes when this returns
@@ -471,10 +534,11 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     a.W = lb.W;
     a.H = lb.H;
     a.n_frames = n_frames;
-    a.items = reinterpret_cast<const ListItem *>(dev);
-    a.bin_start = reinterpret_cast<const uint32_t *>(dev + b_items);
-    a.bin_items = reinterpret_cast<const uint32_t *>(dev + b_items + b_start);
-    a.sel = reinterpret_cast<const uint32_t *>(dev + b_items + b_start + b_bins);
+    a.steps = reinterpret_cast<const uint4 *>(dev);
+    a.items = reinterpret_cast<const ListItem *>(dev + b_steps);
+    a.chunks = reinterpret_cast<const uint2 *>(dev + b_steps + b_items);
+    a.bin_start = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks);
+    a.sel = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks + b_start);
     a.n_sel = (uint32_t)sel.size();
     a.tiles_x = lb.tiles_x;
     a.swap = swap;

@@ -35,8 +35,9 @@ struct ListArgs {
     int W, H;                    // buffer size, W % 8 == 0
     uint32_t n_frames;
     const ListItem * items;
-    const uint32_t * bin_start;  // per tile: first entry of the tile in bin_items; tiles_x*tiles_y + 1 entries
-    const uint32_t * bin_items;  // item indices, ascending within a tile
+    const uint32_t * bin_start;  // per tile: first step of the tile in steps; tiles_x*tiles_y + 1 entries
+    const uint4 * steps;         // what a wave does to its tile, in list order (ListStep)
+    const uint2 * chunks;        // 8-pixel pieces of small items, grouped into batches (ListChunk)
     const uint32_t * sel;        // tiles to process: tile index, bit 31 set = the tile's first item overwrites it whole
     uint32_t n_sel;
     uint32_t tiles_x;
@@ -48,6 +49,16 @@ struct ListArgs {
 };
 
 constexpr int LT = 64;  // tile edge, pixels
+
+// A step is either one item applied to its whole region of the tile (x = LIST_STEP_ITEM | item index), or a batch of
+// chunks (x = kind, y = first chunk, z = number of whole chunks, w = number of partial chunks, whole ones first).
+// A chunk is one 16-byte group of one tile row touched by one small item: x = item index, y = row | group << 6 |
+// pixel mask << 9.  The chunks of a batch come from consecutive items of the same kind (source format, opacity mode,
+// blend function, mask or no mask) that touch pairwise different groups, so they can be applied side by side by the
+// lanes of the wave; that is what turns LVGL's hundreds of one-row descriptors per object into a few wave passes.
+constexpr uint32_t LIST_STEP_ITEM = 0x80000000u;
+// kind = source format | opacity mode (OM_* or OM_OPAQUE; 7 = decide per pixel) << 3 | (blend_fn != normal) << 6
+__host__ __device__ inline uint32_t list_kind(int fmt, int om, bool blended) { return (uint32_t)fmt | ((uint32_t)om << 3) | (blended ? 64u : 0u); }
 
 // Position of pixel (row, col) of the tile in the wave's LDS area, in pixels.  Rows are 128 bytes; the 16-byte
 // chunks of a row are XOR-swizzled with the row's 8-row band so that the column gathers of the 90/270-degree output
@@ -214,6 +225,100 @@ __device__ __forceinline__ void list_dispatch(const ListItem & it, uint4 * tile4
     list_item<SRC, OM_RUNTIME, true>(it, tile4, f, r, lane);
 }
 
+// What blend_group_s / px_core_s read, per lane (the lanes of a batch may work for different items).
+struct LaneView {
+    uint32_t color, opa;
+    int opa_mode, blend_fn, swap;
+    PremultFill pf;
+};
+
+template <int SRC, int OM, bool BLENDED>
+__device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, uint32_t f, int tx, int ty, uint32_t first,
+                                           uint32_t n_full, uint32_t n_part, int lane)
+{
+    const uint2 * ch = a.chunks + first;
+    const uint32_t n = n_full + n_part;
+    uint2 c_next = lane < (int)n ? ch[lane] : make_uint2(0, 0);
+    for(uint32_t base = 0; base < n; base += 64) {
+        const uint32_t idx = base + (uint32_t)lane;
+        const uint2 c = c_next;
+        if(idx + 64 < n) c_next = ch[idx + 64];  // requested now, used in the next pass
+        if(idx >= n) continue;
+        const ListItem & it = a.items[c.x];
+        const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
+        const uint32_t pxmask = (c.y >> 9) & 0xFFu;
+        const int li = row * 8 + ((g ^ (row >> 3)) & 7);
+        const int ax = tx * LT + g * 8 - it.x1, ay = ty * LT + row - it.y1;
+        LaneView v;
+        v.color = it.color;
+        v.opa = it.opa;
+        v.opa_mode = it.opa_mode;
+        v.blend_fn = it.blend_fn;
+        v.swap = a.swap;
+        if(OM == OM_FILL_PREMULT || OM == OM_RUNTIME) v.pf = it.pf;
+        if(idx < n_full) {  // the whole group lies inside the item: vector accesses
+            uint32_t sw[SrcWords<SRC>::N];
+            uint2 mk = make_uint2(0, 0);
+            if(SRC != SRC_FILL)
+                load_src_unaligned<SRC>(it.src, (long long)f * it.src_fs + (long long)ay * it.src_stride + ax, sw);
+            if(it.mask) {
+                u32x2_a1 m = *reinterpret_cast<const u32x2_a1 *>(it.mask + (long long)f * it.mask_fs +
+                                                                 (long long)ay * it.mask_stride + ax);
+                mk = make_uint2(m.x, m.y);
+            }
+            const uint4 d = OM == OM_OPAQUE ? make_uint4(0, 0, 0, 0) : tile4[li];
+            tile4[li] = blend_group_s<SRC, OM, BLENDED>(v, d, sw, mk, 0u, 0u);
+        }
+        else {  // only the pixels of pxmask belong to the item: nothing outside its rectangle is read
+            const uint4 d = tile4[li];
+            uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for(int j = 0; j < 8; j++) {
+                if((pxmask >> j) & 1u) {
+                    uint32_t fg = v.color, m = 0;
+                    list_fetch<SRC>(it, f, ax + j, ay, fg, m);
+                    uint32_t dn = (dw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if(v.swap) dn = px_swap16(dn);
+                    uint32_t res = px_core_s<OM, BLENDED>(v, dn, fg, m, 0u, 0u);
+                    if(v.swap) res = px_swap16(res);
+                    dw[j >> 1] = (j & 1) ? (dw[j >> 1] & 0x0000FFFFu) | (res << 16) : (dw[j >> 1] & 0xFFFF0000u) | res;
+                }
+            }
+            tile4[li] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+        }
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ void batch_dispatch(const ListArgs & a, uint32_t kind, uint4 * tile4, uint32_t f, int tx, int ty,
+                                               uint32_t first, uint32_t n_full, uint32_t n_part, int lane)
+{
+    constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
+    const int om = (int)((kind >> 3) & 7u);
+    if(!(kind & 64u)) {
+        switch(om) {
+            case OM_OPAQUE:
+                if(!own_alpha) return list_batch<SRC, OM_OPAQUE, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                break;
+            case OM_CONST:
+                if(!own_alpha) return list_batch<SRC, OM_CONST, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                break;
+            case OM_MASK: return list_batch<SRC, OM_MASK, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+            case OM_FILL_MASK_OPA:
+                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_MASK_OPA, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                break;
+            case OM_MAP_MASK_OPA:
+                if(SRC != SRC_FILL) return list_batch<SRC, OM_MAP_MASK_OPA, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                break;
+            case OM_FILL_PREMULT:
+                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_PREMULT, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                break;
+            default: break;
+        }
+    }
+    list_batch<SRC, OM_RUNTIME, true>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+}
+
 __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
 {
     __shared__ uint4 lds4[4][LT * LT / 8];
@@ -243,24 +348,37 @@ __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
     }
     wave_lds_fence();
 
-    uint32_t next_id = k0 < k1 ? a.bin_items[k0] : 0u;
+    uint4 st_next = k0 < k1 ? a.steps[k0] : make_uint4(0, 0, 0, 0);
     for(uint32_t k = k0; k < k1; k++) {
-        const ListItem & it = a.items[__builtin_amdgcn_readfirstlane(next_id)];
-        if(k + 1 < k1) next_id = a.bin_items[k + 1];  // requested now, needed after this item
-        ListRegion r;
-        r.x1 = max(it.x1, tx * LT) - tx * LT;
-        r.x2 = min(it.x2, tx * LT + LT - 1) - tx * LT;
-        r.y1 = max(it.y1, ty * LT) - ty * LT;
-        r.y2 = min(it.y2, ty * LT + LT - 1) - ty * LT;
-        if(r.x2 < r.x1 || r.y2 < r.y1) continue;
-        r.ox = tx * LT - it.x1;  // tile-relative -> area-relative
-        r.oy = ty * LT - it.y1;
-        switch(it.fmt) {
-            case SRC_FILL: list_dispatch<SRC_FILL>(it, tile4, f, r, lane); break;
-            case SRC_RGB565: list_dispatch<SRC_RGB565>(it, tile4, f, r, lane); break;
-            case SRC_ARGB8888: list_dispatch<SRC_ARGB8888>(it, tile4, f, r, lane); break;
-            case SRC_RGBA8888: list_dispatch<SRC_RGBA8888>(it, tile4, f, r, lane); break;
-            default: list_dispatch<SRC_ARGB8565>(it, tile4, f, r, lane); break;
+        const uint32_t s_x = __builtin_amdgcn_readfirstlane(st_next.x), s_y = __builtin_amdgcn_readfirstlane(st_next.y);
+        const uint32_t s_z = __builtin_amdgcn_readfirstlane(st_next.z), s_w = __builtin_amdgcn_readfirstlane(st_next.w);
+        if(k + 1 < k1) st_next = a.steps[k + 1];  // requested now, needed after this step
+        if(s_x & LIST_STEP_ITEM) {
+            const ListItem & it = a.items[s_x & ~LIST_STEP_ITEM];
+            ListRegion r;
+            r.x1 = max(it.x1, tx * LT) - tx * LT;
+            r.x2 = min(it.x2, tx * LT + LT - 1) - tx * LT;
+            r.y1 = max(it.y1, ty * LT) - ty * LT;
+            r.y2 = min(it.y2, ty * LT + LT - 1) - ty * LT;
+            if(r.x2 < r.x1 || r.y2 < r.y1) continue;
+            r.ox = tx * LT - it.x1;  // tile-relative -> area-relative
+            r.oy = ty * LT - it.y1;
+            switch(it.fmt) {
+                case SRC_FILL: list_dispatch<SRC_FILL>(it, tile4, f, r, lane); break;
+                case SRC_RGB565: list_dispatch<SRC_RGB565>(it, tile4, f, r, lane); break;
+                case SRC_ARGB8888: list_dispatch<SRC_ARGB8888>(it, tile4, f, r, lane); break;
+                case SRC_RGBA8888: list_dispatch<SRC_RGBA8888>(it, tile4, f, r, lane); break;
+                default: list_dispatch<SRC_ARGB8565>(it, tile4, f, r, lane); break;
+            }
+        }
+        else {
+            switch(s_x & 7u) {
+                case SRC_FILL: batch_dispatch<SRC_FILL>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGB565: batch_dispatch<SRC_RGB565>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_ARGB8888: batch_dispatch<SRC_ARGB8888>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGBA8888: batch_dispatch<SRC_RGBA8888>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                default: batch_dispatch<SRC_ARGB8565>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+            }
         }
         wave_lds_fence();
     }
