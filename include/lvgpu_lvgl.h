@@ -133,6 +133,21 @@ void lvgpu_lvgl_bind(void * lv_draw_sw_init_ctx_fn, void * lv_draw_sw_blend_basi
 /* LV_COLOR_16_SWAP of the host's LVGL build (default 1, the reference firmware's setting, src/lv_conf.h:30). */
 void lvgpu_lvgl_set_color_16_swap(int swap);
 
+/*
+ * Deferred mode (off by default; read by lvgpu_draw_ctx_init).  LVGL's producers issue one lv_draw_sw_blend per row of
+ * a rounded, anti-aliased or text object (libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:118-330, lv_draw_sw_letter.c:
+ * 246-398) -- a 480x320 widget screen is 800-1600 calls.  With deferred mode on, lvgpu_blend only copies the call's
+ * source and mask rectangles into a queue; the queue is drawn as ONE display list (lvgpu_blend_list_batch) when the
+ * buffer is about to be looked at: in lvgpu_flush_cb, lvgpu_wait_for_finish, the layer_* and buffer_copy hooks of
+ * the context (wrapped for this purpose), when draw_ctx->buf changes, and in lvgpu_draw_ctx_deinit.
+ * draw_ctx->wait_for_finish itself is left NULL in this mode, because lv_draw_sw_blend calls it before every single
+ * blend (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:103); all of LVGL's callers check the pointer.  A display
+ * driver that keeps its own flush_cb must therefore call lvgpu_wait_for_finish(drv->draw_ctx) first thing in it.
+ * Code that writes draw_ctx->buf directly between blends, other than through the hooks above, is not supported
+ * in this mode.
+ */
+void lvgpu_lvgl_set_deferred(int on);
+
 /* drv->draw_ctx_init / draw_ctx_deinit / draw_ctx_size (libraries/lvgl/src/hal/lv_hal_disp.h:143-146).
  * init = lv_draw_sw_init_ctx, then blend and wait_for_finish are replaced. */
 void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_ctx);
@@ -167,6 +182,7 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
  * lv_draw_sw_blend_basic (requests outside this library's coverage), flush calls, failed calls. */
 typedef struct {
     uint64_t blend_gpu, blend_delegated, flush_gpu, errors;
+    uint64_t blend_lists; /* deferred mode: display lists submitted */
 } lvgpu_lvgl_stats_t;
 void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out);
 void lvgpu_lvgl_reset_stats(void);

@@ -343,8 +343,18 @@ static int g_fb_w, g_fb_h;
 static int g_flush_calls;
 static int g_px_bytes = 2; /* 3 when the scene display has screen_transp (ARGB8565 draw buffer) */
 
+/* What a display driver with its own flush_cb has to call first when the draw context defers its work
+ * (the plug-in's wait-for-finish entry point); NULL for LVGL's software context. */
+static void (*g_pre_flush)(lv_draw_ctx_t *);
+
+REF_API void ref_scene_set_pre_flush(void * fn)
+{
+    g_pre_flush = (void (*)(lv_draw_ctx_t *))fn;
+}
+
 static void capture_flush(lv_disp_drv_t * drv, const lv_area_t * a, lv_color_t * p)
 {
+    if(g_pre_flush) g_pre_flush(drv->draw_ctx);
     int w = a->x2 - a->x1 + 1;
     const uint8_t * src = (const uint8_t *)p;
     uint8_t * fb = (uint8_t *)g_fb1;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 class Stats(C.Structure):
     _fields_ = [("blend_gpu", C.c_uint64), ("blend_delegated", C.c_uint64), ("flush_gpu", C.c_uint64),
-                ("errors", C.c_uint64)]
+                ("errors", C.c_uint64), ("blend_lists", C.c_uint64)]
 
 
 class FlushCfg(C.Structure):
@@ -27,9 +27,11 @@ def _addr(fn):
     return C.cast(fn, C.c_void_p)
 
 
-@pytest.fixture(scope="module", params=[1, 0])
+@pytest.fixture(scope="module", params=[(1, 0), (0, 0), (1, 1), (0, 1)], ids=["swap1", "swap0", "swap1-deferred",
+                                                                               "swap0-deferred"])
 def world(request, gpu, oracle):
-    swap = request.param
+    """(LV_COLOR_16_SWAP, deferred): deferred = blend calls are queued and drawn as one display list per flush."""
+    swap, deferred = request.param
     R = oracle.ref(swap)
     if R is None:
         pytest.skip("oracle/_ref (real LVGL) not present")
@@ -37,8 +39,13 @@ def world(request, gpu, oracle):
     L = _lib.lib()
     L.lvgpu_lvgl_bind(_addr(R.lv_draw_sw_init_ctx), _addr(R.lv_draw_sw_blend_basic), _addr(R.lv_disp_flush_ready))
     L.lvgpu_lvgl_set_color_16_swap(swap)
+    L.lvgpu_lvgl_set_deferred(deferred)
+    # the harness' own flush_cb does what a driver with its own flush_cb has to do in deferred mode
+    R.ref_scene_set_pre_flush(_addr(L.lvgpu_wait_for_finish) if deferred else None)
     yield swap, R, L
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)  # drop the GPU context before the library goes away
+    R.ref_scene_set_pre_flush(None)
+    L.lvgpu_lvgl_set_deferred(0)
     L.lvgpu_lvgl_bind(None, None, None)
 
 
@@ -57,7 +64,7 @@ def _render_sw(R, w, h, scene, flags=0):
 
 @pytest.mark.parametrize("scene", [0, 1, 2])
 @pytest.mark.parametrize("res,flags", [((320, 480), 0), ((480, 320), 0), ((320, 480), 1), ((320, 240), 2), ((200, 96), 3)])
-def test_widget_scene_through_gpu_blend(world, scene, res, flags):
+def test_widget_scene_through_gpu_blend(world, scene, res, flags, request):
     """flags bit 0: anti-aliasing off (mask thresholding); bit 1: transparent screen (ARGB8565 draw buffer)."""
     swap, R, L = world
     w, h = res
@@ -73,6 +80,8 @@ def test_widget_scene_through_gpu_blend(world, scene, res, flags):
     L.lvgpu_lvgl_get_stats(C.byref(st))
     assert st.blend_gpu > 0 and st.blend_delegated == 0 and st.errors == 0
     assert np.array_equal(got, sw), "%d pixels differ" % int((got != sw).sum())
+    if request.node.callspec.params["world"][1]:  # deferred: hundreds of blend calls, a handful of submissions
+        assert 1 <= st.blend_lists <= 4 and st.blend_gpu > 100 * st.blend_lists
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])

@@ -1,0 +1,51 @@
+"""Live LVGL (oracle/_ref, the real library) rendering one widget scene per refresh: LVGL's software blend, the GPU
+plug-in in immediate mode (one staged blend per call) and in deferred mode (one display list per flush).
+Run on the GPU box:  python tools/bench_dropin.py"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import lvref_py as O  # noqa: E402
+from vvc_amd import _lib, lvgpu  # noqa: E402
+
+
+def addr(fn):
+    return C.cast(fn, C.c_void_p)
+
+
+def main():
+    W, H, scene, reps = 480, 320, 2, 20
+    lvgpu.init(0)
+    R = O.ref(1)
+    L = _lib.lib()
+    L.lvgpu_lvgl_bind(addr(R.lv_draw_sw_init_ctx), addr(R.lv_draw_sw_blend_basic), addr(R.lv_disp_flush_ready))
+    L.lvgpu_lvgl_set_color_16_swap(1)
+    frames = {}
+    for mode in ("lvgl_sw", "gpu_immediate", "gpu_deferred"):
+        L.lvgpu_lvgl_set_deferred(1 if mode == "gpu_deferred" else 0)
+        R.ref_scene_set_pre_flush(addr(L.lvgpu_wait_for_finish) if mode == "gpu_deferred" else None)
+        if mode == "lvgl_sw":
+            R.ref_scene_display(W, H, None, None, 0, None, None, 1, 0)
+        else:
+            R.ref_scene_display(W, H, addr(L.lvgpu_draw_ctx_init), addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                                None, None, 1, 0)
+        R.ref_scene_build(scene)
+        R.ref_scene_refresh()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            R.ref_scene_build(scene)   # invalidates the screen again
+            R.ref_scene_refresh()
+        dt = (time.perf_counter() - t0) / reps
+        frames[mode] = np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint16)), shape=(H * W,)).copy()
+        print("%-14s %8.2f ms per refresh of scene %d (%dx%d)" % (mode, dt * 1e3, scene, W, H), flush=True)
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+    R.ref_scene_set_pre_flush(None)
+    print("identical frames:", all(np.array_equal(frames["lvgl_sw"], v) for v in frames.values()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,9 +1,13 @@
 // lvgpu_lvgl_shim.cpp -- LVGL-signature callbacks (include/lvgpu_lvgl.h) on top of the batched C ABI.
 //
 // Single-frame, host-buffer versions of the plug-in points of LVGL 8.x: lv_draw_sw_ctx_t.blend,
-// lv_draw_ctx_t.wait_for_finish, lv_disp_drv_t.draw_ctx_init/deinit/size and lv_disp_drv_t.flush_cb.  Each call
-// stages the touched rectangle into device memory, runs the batch kernels with n_frames = 1 and copies the
-// result back before it returns.
+// lv_draw_ctx_t.wait_for_finish, lv_disp_drv_t.draw_ctx_init/deinit/size and lv_disp_drv_t.flush_cb.
+// Immediate mode (default): each blend call stages the touched rectangle into device memory, runs the batch
+// kernels with n_frames = 1 and copies the result back before it returns.
+// Deferred mode (lvgpu_lvgl_set_deferred): blend calls only copy their source/mask rectangles into a queue; the
+// queue is submitted as ONE display list (draw buffer up, one launch, draw buffer down) when something is about
+// to look at the buffer -- lvgpu_flush_cb, lvgpu_wait_for_finish, the layer and buffer_copy hooks, a change of
+// draw_ctx->buf, context deinit.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -11,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/lvgpu_lvgl.h"
 
@@ -24,7 +29,42 @@ init_ctx_fn g_sw_init_ctx = nullptr;
 blend_fn g_sw_blend_basic = nullptr;
 flush_ready_fn g_flush_ready = nullptr;
 int g_swap = 1;
-std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0};
+int g_deferred = 0;
+std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0};
+
+typedef void * (*layer_init_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
+typedef void (*layer_adjust_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
+typedef void (*layer_blend_fn)(lvgpu_lv_draw_ctx_t *, void *, const void *);
+typedef void (*layer_destroy_fn)(lvgpu_lv_draw_ctx_t *, void *);
+typedef void (*buffer_copy_fn)(lvgpu_lv_draw_ctx_t *, void *, int16_t, const lvgpu_lv_area_t *, void *, int16_t,
+                               const lvgpu_lv_area_t *);
+
+// One queued blend: the clipped rectangle and where its private copies of source and mask lie in the arena.
+struct QItem {
+    lvgpu_area_t area;
+    size_t src_off, mask_off;
+    bool has_src, has_mask;
+    uint16_t color;
+    uint8_t opa, mode;
+};
+struct Queue {
+    std::vector<QItem> items;
+    std::vector<uint8_t> arena;
+    std::vector<lvgpu_blend_batch_t> batch;
+    void * buf = nullptr;          // the host draw buffer the queued items draw into
+    lvgpu_area_t buf_area{0, 0, 0, 0};
+    bool transp = false;
+    void * d_fb = nullptr;
+    size_t fb_cap = 0;
+    void * d_arena = nullptr;
+    size_t arena_cap = 0;
+    // the software implementations behind the hooks this library wraps
+    layer_init_fn sw_layer_init = nullptr;
+    layer_adjust_fn sw_layer_adjust = nullptr;
+    layer_blend_fn sw_layer_blend = nullptr;
+    layer_destroy_fn sw_layer_destroy = nullptr;
+    buffer_copy_fn sw_buffer_copy = nullptr;
+};
 
 // lv_draw_sw_ctx_t (libraries/lvgl/src/draw/sw/lv_draw_sw.h:32-37) extended the way GPU back-ends extend it
 // (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.h: typedef lv_draw_sw_ctx_t lv_draw_stm32_dma2d_ctx_t).
@@ -39,6 +79,7 @@ struct ShimCtx {
     void * d_src;
     void * d_mask;
     size_t cap_px;
+    Queue * q;  // deferred mode only
 };
 constexpr uint32_t MAGIC = 0x4C564750u;  // "LVGP"
 
@@ -83,6 +124,102 @@ void flush_ready(lvgpu_lv_disp_drv_t * drv)
     }
 }
 
+// Submit the queue: draw buffer to the device, the whole list in one call, draw buffer back.
+void submit(ShimCtx * s)
+{
+    Queue * q = s->q;
+    if(q == nullptr || q->items.empty()) return;
+    const int W = q->buf_area.x2 - q->buf_area.x1 + 1, H = q->buf_area.y2 - q->buf_area.y1 + 1;
+    const size_t bpp = q->transp ? 3 : 2;
+    const size_t fb_bytes = (size_t)W * H * bpp;
+    if(fb_bytes > q->fb_cap) {
+        if(q->d_fb) HIP_OR_DIE(hipFree(q->d_fb));
+        HIP_OR_DIE(hipMalloc(&q->d_fb, fb_bytes));
+        q->fb_cap = fb_bytes;
+    }
+    if(q->arena.size() > q->arena_cap) {
+        if(q->d_arena) HIP_OR_DIE(hipFree(q->d_arena));
+        q->arena_cap = q->arena.size() * 2;
+        HIP_OR_DIE(hipMalloc(&q->d_arena, q->arena_cap));
+    }
+    hipStream_t st = s->stream;
+    HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
+    if(!q->arena.empty()) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data(), q->arena.size(), hipMemcpyHostToDevice, st));
+    q->batch.resize(q->items.size());
+    for(size_t i = 0; i < q->items.size(); i++) {
+        const QItem & it = q->items[i];
+        lvgpu_blend_batch_t & b = q->batch[i];
+        memset(&b, 0, sizeof(b));
+        b.dst = q->d_fb;
+        b.dst_frame_stride = (int64_t)W * H;
+        b.buf_area = q->buf_area;
+        b.clip_area = it.area;
+        b.blend_area = it.area;
+        b.mask_area = it.area;
+        b.src = it.has_src ? reinterpret_cast<uint8_t *>(q->d_arena) + it.src_off : nullptr;
+        b.src_format = it.has_src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
+        b.mask = it.has_mask ? reinterpret_cast<uint8_t *>(q->d_arena) + it.mask_off : nullptr;
+        b.mask_res = LVGPU_MASK_RES_CHANGED;
+        b.n_frames = 1;
+        b.color = it.color;
+        b.opa = it.opa;
+        b.blend_mode = it.mode;
+        b.color_16_swap = (uint8_t)g_swap;
+        b.dst_argb8565 = q->transp ? 1 : 0;
+    }
+    int rc = lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
+    if(rc != LVGPU_OK) {
+        fprintf(stderr, "lvgpu: lvgpu_blend_list_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+        g_errors++;
+        abort();
+    }
+    HIP_OR_DIE(hipMemcpyAsync(q->buf, q->d_fb, fb_bytes, hipMemcpyDeviceToHost, st));
+    HIP_OR_DIE(hipStreamSynchronize(st));
+    q->items.clear();
+    q->arena.clear();
+    g_lists++;
+}
+
+inline ShimCtx * shim_of(lvgpu_lv_draw_ctx_t * c)
+{
+    ShimCtx * s = reinterpret_cast<ShimCtx *>(c);
+    return (s && s->magic == MAGIC) ? s : nullptr;
+}
+
+// Hooks at which LVGL's own code reads, replaces or frees the buffer the queue draws into
+// (libraries/lvgl/src/draw/sw/lv_draw_sw_layer.c:42-141, libraries/lvgl/src/draw/sw/lv_draw_sw.c:80-101).
+void * hook_layer_init(lvgpu_lv_draw_ctx_t * c, void * layer, int flags)
+{
+    ShimCtx * s = shim_of(c);
+    submit(s);
+    return s->q->sw_layer_init ? s->q->sw_layer_init(c, layer, flags) : nullptr;
+}
+void hook_layer_adjust(lvgpu_lv_draw_ctx_t * c, void * layer, int flags)
+{
+    ShimCtx * s = shim_of(c);
+    submit(s);
+    if(s->q->sw_layer_adjust) s->q->sw_layer_adjust(c, layer, flags);
+}
+void hook_layer_blend(lvgpu_lv_draw_ctx_t * c, void * layer, const void * dsc)
+{
+    ShimCtx * s = shim_of(c);
+    submit(s);  // the layer buffer is about to be read as an image
+    if(s->q->sw_layer_blend) s->q->sw_layer_blend(c, layer, dsc);
+}
+void hook_layer_destroy(lvgpu_lv_draw_ctx_t * c, void * layer)
+{
+    ShimCtx * s = shim_of(c);
+    submit(s);
+    if(s->q->sw_layer_destroy) s->q->sw_layer_destroy(c, layer);
+}
+void hook_buffer_copy(lvgpu_lv_draw_ctx_t * c, void * dest_buf, int16_t dest_stride, const lvgpu_lv_area_t * dest_area,
+                      void * src_buf, int16_t src_stride, const lvgpu_lv_area_t * src_area)
+{
+    ShimCtx * s = shim_of(c);
+    submit(s);
+    if(s->q->sw_buffer_copy) s->q->sw_buffer_copy(c, dest_buf, dest_stride, dest_area, src_buf, src_stride, src_area);
+}
+
 }  // namespace
 
 extern "C" {
@@ -95,6 +232,8 @@ void lvgpu_lvgl_bind(void * init_ctx, void * blend_basic, void * flush_ready_p)
 }
 
 void lvgpu_lvgl_set_color_16_swap(int swap) { g_swap = swap ? 1 : 0; }
+
+void lvgpu_lvgl_set_deferred(int on) { g_deferred = on ? 1 : 0; }
 
 size_t lvgpu_draw_ctx_size(void) { return sizeof(ShimCtx); }
 
@@ -117,6 +256,23 @@ void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_c
     int dev = -1;
     HIP_OR_DIE(hipGetDevice(&dev));  // the calling thread's current device; fails when there is none
     HIP_OR_DIE(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if(g_deferred) {
+        Queue * q = new Queue();
+        s->q = q;
+        // lv_draw_sw_blend calls wait_for_finish before EVERY blend (lv_draw_sw_blend.c:103), which would submit
+        // the queue item by item; every caller checks the pointer, so it is cleared and the hooks below submit.
+        s->base_draw.wait_for_finish = nullptr;
+        q->sw_layer_init = (layer_init_fn)s->base_draw.layer_init;
+        q->sw_layer_adjust = (layer_adjust_fn)s->base_draw.layer_adjust;
+        q->sw_layer_blend = (layer_blend_fn)s->base_draw.layer_blend;
+        q->sw_layer_destroy = (layer_destroy_fn)s->base_draw.layer_destroy;
+        q->sw_buffer_copy = (buffer_copy_fn)s->base_draw.buffer_copy;
+        s->base_draw.layer_init = (void *)hook_layer_init;
+        s->base_draw.layer_adjust = (void *)hook_layer_adjust;
+        s->base_draw.layer_blend = (void *)hook_layer_blend;
+        s->base_draw.layer_destroy = (void *)hook_layer_destroy;
+        s->base_draw.buffer_copy = hook_buffer_copy;
+    }
 }
 
 void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_ctx)
@@ -124,6 +280,12 @@ void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw
     (void)drv;
     ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
     if(s->magic == MAGIC) {
+        if(s->q) {
+            submit(s);  // e.g. a canvas or snapshot drawn through a temporary context expects its pixels now
+            if(s->q->d_fb) (void)hipFree(s->q->d_fb);
+            if(s->q->d_arena) (void)hipFree(s->q->d_arena);
+            delete s->q;
+        }
         if(s->stream) (void)hipStreamSynchronize(s->stream);
         if(s->d_dst) (void)hipFree(s->d_dst);
         if(s->d_src) (void)hipFree(s->d_src);
@@ -136,7 +298,9 @@ void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw
 void lvgpu_wait_for_finish(lvgpu_lv_draw_ctx_t * draw_ctx)
 {
     ShimCtx * s = reinterpret_cast<ShimCtx *>(draw_ctx);
-    if(s->magic == MAGIC && s->stream) HIP_OR_DIE(hipStreamSynchronize(s->stream));
+    if(s == nullptr || s->magic != MAGIC) return;
+    if(s->q) submit(s);
+    if(s->stream) HIP_OR_DIE(hipStreamSynchronize(s->stream));
 }
 
 void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_dsc_t * dsc)
@@ -148,6 +312,7 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     // every LVGL GPU back-end (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130,207): a display
     // with a custom set_px_cb, whose pixel format only that callback knows.
     if(drv->set_px_cb != nullptr) {
+        if(s->q) submit(s);
         g_blend_delegated++;
         if(g_sw_blend_basic) g_sw_blend_basic(draw_ctx, dsc);
         else {
@@ -192,6 +357,42 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
     }
 
     const size_t px = (size_t)w * h;
+    if(s->q) {  // deferred: keep private copies of the rectangles, draw later
+        Queue * q = s->q;
+        const lvgpu_area_t ba{draw_ctx->buf_area->x1, draw_ctx->buf_area->y1, draw_ctx->buf_area->x2, draw_ctx->buf_area->y2};
+        const bool transp = drv->screen_transp != 0;
+        if(!q->items.empty() && (q->buf != draw_ctx->buf || memcmp(&q->buf_area, &ba, sizeof(ba)) != 0 || q->transp != transp))
+            submit(s);  // the context was pointed at another buffer (layers do that)
+        q->buf = draw_ctx->buf;
+        q->buf_area = ba;
+        q->transp = transp;
+        QItem it;
+        it.area = lvgpu_area_t{a.x1, a.y1, a.x2, a.y2};
+        it.has_src = src != nullptr;
+        it.has_mask = mask != nullptr;
+        it.src_off = it.mask_off = 0;
+        it.color = dsc->color;
+        it.opa = dsc->opa;
+        it.mode = dsc->blend_mode;
+        if(src) {
+            it.src_off = (q->arena.size() + 15) & ~(size_t)15;
+            q->arena.resize(it.src_off + px * 2);
+            for(int y = 0; y < h; y++)
+                memcpy(q->arena.data() + it.src_off + (size_t)y * w * 2, src + (size_t)y * src_stride, (size_t)w * 2);
+        }
+        if(mask) {
+            it.mask_off = (q->arena.size() + 15) & ~(size_t)15;
+            q->arena.resize(it.mask_off + px);
+            if(transp && src == nullptr && dsc->opa >= 253)
+                memcpy(q->arena.data() + it.mask_off, mask, px);  // fill_argb's opaque masked loop: one run of w*h bytes
+            else
+                for(int y = 0; y < h; y++)
+                    memcpy(q->arena.data() + it.mask_off + (size_t)y * w, mask + (size_t)y * mask_stride, (size_t)w);
+        }
+        q->items.push_back(it);
+        g_blend_gpu++;
+        return;
+    }
     ensure_capacity(s, px);
     hipStream_t st = s->stream;
     const bool overwrite = mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0 && !drv->screen_transp;
@@ -248,6 +449,7 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         fprintf(stderr, "lvgpu_flush_cb: drv->user_data must point to a lvgpu_flush_cfg_t with a draw_bitmap sink\n");
         abort();
     }
+    if(drv->draw_ctx) lvgpu_wait_for_finish(drv->draw_ctx);  // deferred mode: the queued blends are drawn now
     const int x_start = area->x1, x_end = area->x2, y_start = area->y1, y_end = area->y2;
     const int W = x_end - x_start + 1, H = y_end - y_start + 1;
     const int rot = cfg->sw_rotate;
@@ -359,6 +561,7 @@ void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out)
     out->blend_delegated = g_blend_delegated;
     out->flush_gpu = g_flush_gpu;
     out->errors = g_errors;
+    out->blend_lists = g_lists;
 }
 void lvgpu_lvgl_reset_stats(void)
 {
@@ -366,6 +569,7 @@ void lvgpu_lvgl_reset_stats(void)
     g_blend_delegated = 0;
     g_flush_gpu = 0;
     g_errors = 0;
+    g_lists = 0;
 }
 
 }  // extern "C"
