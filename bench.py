@@ -6,6 +6,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
         (lv_draw_sw_blend, map_normal with per-pixel alpha) fused with the 90-degree flush rotation into
         the 320x480 panel image -- 4 B + 2 B read, 2 B + 2 B written per pixel = 10 algorithmic bytes/px.
     workload "blend": the blend alone (8 bytes/px).   workload "rotate": the flush rotation alone (4 bytes/px).
+    workload "scene": a widget scene recorded from the real LVGL (tests/golden/scene2_*.npz, 1649 blend descriptors)
+        replayed over every frame as ONE display list with the fused flush; bytes/px counts what must move (draw
+        buffer and panel image written once each, 4 bytes/px) -- this kernel is bound by VALU issue, not by HBM.
 Frames are sharded over ranks (one process per GPU), there is no data-path collective; torch.distributed is used
 only for the barrier and the max-over-ranks time.
 
@@ -26,7 +29,7 @@ from vvc_amd import lvgpu, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 SEED_DST, SEED_SRC, SEED_MASK = 0x5EED0001, 0x5EED0002, 0x5EED0003
-BYTES_PER_PX = {"blend_flush": 10, "blend": 8, "rotate": 4, "blend_rgb565a8": 7, "blend_flush_rgb565a8": 9}
+BYTES_PER_PX = {"blend_flush": 10, "blend": 8, "rotate": 4, "blend_rgb565a8": 7, "blend_flush_rgb565a8": 9, "scene": 4}
 
 
 def parse():
@@ -143,9 +146,25 @@ def main():
         a8 = lvgpu.synth(lvgpu.SYNTH_MASK_UI if args.mask == "ui" else lvgpu.SYNTH_MASK_UNI, SEED_MASK, first, (n, H, W))
         dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
     swap_bytes = 0 if args.swap else 1
+    blist = None
+    if args.workload == "scene":
+        assert (W, H) == (480, 320), "the recorded scenes are 480x320"
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from util import load_scene
+        _fb, rec = load_scene(os.path.join(ROOT, "tests", "golden", "scene2_f0_swap%d.npz" % args.swap))
+        dscs, keep = [], []
+        for r in rec:
+            s16 = None if r["src"] is None else torch.from_numpy(r["src"].view("int16").copy()).cuda()
+            m8 = None if r["mask"] is None else torch.from_numpy(r["mask"].copy()).cuda()
+            keep += [s16, m8]
+            dscs.append(lvgpu.BlendDsc(r["area"], src_buf=s16, color=r["color"], mask_buf=m8, opa=r["opa"],
+                                       blend_mode=r["blend_mode"]))
+        blist = lvgpu.BlendList(ctx, dscs)
 
     def step(stream=None):
-        if args.workload.startswith("blend_flush"):
+        if blist is not None:
+            blist.run_flush(rot, swap_bytes=swap_bytes, out=out, stream=stream)
+        elif args.workload.startswith("blend_flush"):
             lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
         elif args.workload.startswith("blend"):
             lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
@@ -207,7 +226,10 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {
-                "workload": "%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
+                "workload": ("scene: %d LVGL blend descriptors (recorded widget scene) as one display list + flush, "
+                             "LV_COLOR_16_SWAP %d, %dx%d logical, rotation %d, %d frames per GPU"
+                             % (blist.n, args.swap, W, H, rot * 90, n)) if blist is not None else
+                            "%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
                             "rotation %d, %d frames per GPU" % (args.workload, args.mask, args.swap, W, H, rot * 90, n),
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
             },

@@ -433,6 +433,50 @@ struct ListBuilder {
     }
 };
 
+// Pinned host memory through which a list's tables reach the device, one per calling thread, kept for the life of
+// the thread.  The copy is asynchronous; the event tells the next call on this thread when the bytes have left.
+struct ListStaging {
+    uint8_t * host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int device = -1;  // the event belongs to the device that was current when it was created
+    int acquire(size_t bytes, uint8_t ** out)
+    {
+        if(pending) {
+            HIP_TRY(hipEventSynchronize(ev));
+            pending = false;
+        }
+        int cur = -1;
+        HIP_TRY(hipGetDevice(&cur));
+        if(ev != nullptr && cur != device) {
+            HIP_TRY(hipEventDestroy(ev));
+            ev = nullptr;
+        }
+        if(ev == nullptr) {
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            device = cur;
+        }
+        if(bytes > cap) {
+            if(host) HIP_TRY(hipHostFree(host));
+            host = nullptr;
+            cap = 0;
+            const size_t want = std::max<size_t>(bytes * 2, 1 << 20);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host), want, hipHostMallocPortable));
+            cap = want;
+        }
+        *out = host;
+        return LVGPU_OK;
+    }
+    int release(hipStream_t st)
+    {
+        HIP_TRY(hipEventRecord(ev, st));
+        pending = true;
+        return LVGPU_OK;
+    }
+};
+thread_local ListStaging g_stage;
+
 // An item's part of a tile with fewer pixels than this is cut into chunks and batched with its neighbours in the
 // list; larger parts are walked by the whole wave on their own.
 constexpr int LIST_BIG_REGION = 512;
@@ -511,8 +555,11 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     const size_t b_steps = steps.size() * sizeof(uint4), b_items = lb.items.size() * sizeof(ListItem),
                  b_chunks = chunks.size() * sizeof(uint2), b_start = bin_start.size() * 4, b_sel = sel.size() * 4;
     static_assert(sizeof(ListItem) % 8 == 0, "chunks must stay 8-byte aligned behind the items");
-    std::vector<uint8_t> blob(b_steps + b_items + b_chunks + b_start + b_sel);
-    uint8_t * w = blob.data();
+    const size_t blob_bytes = b_steps + b_items + b_chunks + b_start + b_sel;
+    uint8_t * host = nullptr;
+    int rc_stage = g_stage.acquire(blob_bytes, &host);
+    if(rc_stage != LVGPU_OK) return rc_stage;
+    uint8_t * w = host;
     auto put = [&w](const void * p, size_t n) {
         if(n) memcpy(w, p, n);
         w += n;
@@ -523,9 +570,10 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     put(bin_start.data(), b_start);
     put(sel.data(), b_sel);
     uint8_t * dev = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob.size(), st));
-    // pageable source: the runtime has consumed the host bytes when this returns
-    HIP_TRY(hipMemcpyAsync(dev, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob_bytes, st));
+    HIP_TRY(hipMemcpyAsync(dev, host, blob_bytes, hipMemcpyHostToDevice, st));
+    rc_stage = g_stage.release(st);
+    if(rc_stage != LVGPU_OK) return rc_stage;
 
     ListArgs a;
     memset(&a, 0, sizeof(a));

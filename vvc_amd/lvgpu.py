@@ -214,6 +214,30 @@ def blend_list_flush(ctx, dscs, rotation, swap_bytes=0, clips=None, out=None, st
     return out
 
 
+class BlendList:
+    """A display list marshalled once and replayed many times (the descriptors, their sources and masks and ctx.buf
+    must stay alive and in place)."""
+
+    def __init__(self, ctx, dscs, clips=None):
+        self.ctx, self.n = ctx, len(dscs)
+        self._keep = (list(dscs), clips)
+        self.arr = _fill_list(ctx, dscs, clips)
+        self.geom = _fill_batch(ctx, BlendDsc(ctx.buf_area))
+
+    def run(self, stream=None):
+        check(_lib.lib().lvgpu_blend_list_batch(self.arr, self.n, _stream(stream)))
+
+    def run_flush(self, rotation, swap_bytes=0, out=None, stream=None):
+        n, h, w = self.ctx.buf.shape[:3]
+        if out is None:
+            shape = (n, w, h) if rotation in (LV_DISP_ROT_90, LV_DISP_ROT_270) else (n, h, w)
+            out = torch.empty(shape, dtype=self.ctx.buf.dtype, device=self.ctx.buf.device)
+        check(_lib.lib().lvgpu_blend_list_flush_batch(C.byref(self.geom), self.arr, self.n, out.data_ptr(),
+                                                       (out.stride(0) if n > 1 else h * w), rotation, int(swap_bytes),
+                                                       _stream(stream)))
+        return out
+
+
 def color_from_rgb888(xrgb, color_16_swap=1, stream=None):
     """lv_color_hex over a uint32/int32 tensor of 0x00RRGGBB words."""
     out = torch.empty(xrgb.shape, dtype=torch.int16, device=xrgb.device)
