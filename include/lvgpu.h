@@ -198,6 +198,25 @@ int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, v
 int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items,
                                  void * out, int64_t out_frame_stride, int32_t rotation, int32_t swap_bytes, void * stream);
 
+/*
+ * The transport chunks of the reference's flush callback (src/lv_port.c:466-566): the flushed area is cut into pieces of
+ * at most trans_size pixels -- whole source columns for 90/270 degrees (:482-487, :500-521), whole rows otherwise
+ * (:488-494, :522-543) -- and each piece is sent to the panel as one rectangle.  Every piece is a contiguous slice of
+ * the panel image that lvgpu_flush_rotate_batch / lvgpu_blend_flush_batch write for the area, so a transport can send
+ * straight from that image: out[i] gets the rectangle (end exclusive, as esp_lcd_panel_draw_bitmap takes it, :556) and
+ * the slice.  hor_res / ver_res are drv->hor_res / drv->ver_res.  Host arithmetic only.  Returns the number of
+ * chunks (at most max_chunks are written; pass out == NULL to count) or a negative LVGPU_ERR_*.
+ */
+typedef struct {
+    int32_t x_start, y_start, x_end, y_end; /* panel rectangle, end exclusive                                          */
+    int64_t offset_px;                      /* first pixel of the piece in the area's panel image                      */
+    int32_t n_px;
+    int32_t reserved;
+} lvgpu_flush_chunk_t;
+
+int lvgpu_flush_chunks(const lvgpu_area_t * area, int32_t hor_res, int32_t ver_res, int32_t rotation, uint32_t trans_size,
+                       lvgpu_flush_chunk_t * out, int32_t max_chunks);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Colour conversion (libraries/lvgl/src/misc/lv_color.h)                                                       */
 /* ------------------------------------------------------------------------------------------------------------ */

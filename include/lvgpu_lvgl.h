@@ -178,6 +178,15 @@ typedef struct {
 
 void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvgpu_lv_color_t * color_p);
 
+/*
+ * LVGPU_ROT_* follow the naming of the reference's flush callback (src/lv_port.c:500-543).  LVGL's OWN software
+ * rotation (drv->sw_rotate, libraries/lvgl/src/core/lv_refr.c:1108-1126,1226) names the two quarter turns the other
+ * way round: what it flushes for drv->rotated == LV_DISP_ROT_90 is the LVGPU_ROT_270 image and vice versa (checked
+ * against whole frames rotated by LVGL itself, tests/golden/lvgl_sw_rotate_swap*.npz).  This returns the LVGPU_ROT_*
+ * value that reproduces LVGL's output for a given drv->rotated, or -1 for a value outside 0..3.
+ */
+int lvgpu_rotation_for_lvgl_sw_rotate(int lv_disp_rot);
+
 /* Counters for tests and integration checks: blend calls executed on the GPU, blend calls handed to the host's
  * lv_draw_sw_blend_basic (requests outside this library's coverage), flush calls, failed calls. */
 typedef struct {

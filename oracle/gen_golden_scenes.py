@@ -39,6 +39,18 @@ def main():
             path = os.path.join(GOLD, "scene%d_f%d_swap%d.npz" % (scene, flags, swap))
             np.savez_compressed(path, **pack(fb, items))
             print(path, len(items), "descriptors", os.path.getsize(path), "bytes")
+        # LVGL's own software rotation (drv.sw_rotate, libraries/lvgl/src/core/lv_refr.c:1084-1265) of whole frames:
+        # the un-rotated logical frame and what LVGL flushes to a panel for drv.rotated = 90/180/270.
+        arrays = {}
+        for LW, LH in ((480, 320), (320, 480), (200, 96)):
+            arrays["logical_%dx%d" % (LW, LH)] = O.render_scene(L, LW, LH, 2, 0)
+            for r in (1, 2, 3):
+                hor, ver = (LW, LH) if r == 2 else (LH, LW)
+                arrays["lv_rot%d_%dx%d" % (r, LW, LH)] = O.render_scene(L, hor, ver, 2, 4 | (r << 3))
+        L.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+        path = os.path.join(GOLD, "lvgl_sw_rotate_swap%d.npz" % swap)
+        np.savez_compressed(path, **arrays)
+        print(path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

@@ -253,6 +253,15 @@ def ref(swap=1):
     return _ref[swap]
 
 
+def render_scene(L, hor_res, ver_res, scene, flags=0):
+    """Widget scene `scene` rendered by the real LVGL on a hor_res x ver_res (physical) display; flags as
+    ref_scene_display (bit 2 + bits 3-4: LVGL's own software rotation).  Returns the frame buffer [ver_res, hor_res]."""
+    assert L.ref_scene_display(hor_res, ver_res, None, None, 0, None, None, 0 if flags & 4 else 1, flags) == 0
+    L.ref_scene_build(scene)
+    L.ref_scene_refresh()
+    return np.ctypeslib.as_array(C.cast(L.ref_scene_fb(), C.POINTER(C.c_uint16)), shape=(ver_res, hor_res)).copy()
+
+
 def recorded_scene(L, w, h, scene, flags=0):
     """Render widget scene `scene` with the real LVGL while recording every blend descriptor its producers issue.
     Returns (frame buffer as LVGL drew it [h, w] uint16, list of dicts area/src/mask/color/opa/blend_mode)."""

@@ -370,7 +370,9 @@ static void capture_flush(lv_disp_drv_t * drv, const lv_area_t * a, lv_color_t *
 /* Register the scene display.  init/deinit/size == NULL/0 keeps LVGL's software context; flush == NULL keeps the
  * capturing flush above.  full_refresh as in the port (src/lv_port.c:242). */
 /* flags: bit 0 = anti-aliasing off (masks are thresholded, lv_draw_sw_blend.c:150-156), bit 1 = screen_transp
- * (ARGB8565 draw buffer, 3 bytes per pixel) */
+ * (ARGB8565 draw buffer, 3 bytes per pixel), bit 2 = LVGL's own software rotation (drv.sw_rotate,
+ * libraries/lvgl/src/core/lv_refr.c:1084-1265) with drv.rotated = bits 3-4; hor_res/ver_res are then the PHYSICAL
+ * size, the scene is laid out on the swapped logical size and the frame buffer collects the rotated chunks */
 REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * deinit, size_t ctx_size, void * flush,
                               void * user_data, int full_refresh, int flags)
 {
@@ -400,6 +402,11 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
     g_drv1.user_data = user_data;
     if(flags & 1) g_drv1.antialiasing = 0;
     if(flags & 2) g_drv1.screen_transp = 1;
+    if(flags & 4) {
+        g_drv1.sw_rotate = 1;
+        g_drv1.rotated = (flags >> 3) & 3;
+        g_drv1.full_refresh = 0; /* lv_refr.c:1178-1181 refuses to rotate a full-refreshed display */
+    }
     if(init) {
         g_drv1.draw_ctx_init = (ctx_init_fn)init;
         g_drv1.draw_ctx_deinit = (ctx_init_fn)deinit;
@@ -475,7 +482,7 @@ REF_API int ref_scene_build(int id)
     lv_obj_set_style_bg_color(scr, lv_color_hex(0x203040), 0);
     lv_obj_set_style_bg_opa(scr, g_drv1.screen_transp ? LV_OPA_60 : LV_OPA_COVER, 0);
     if(g_drv1.screen_transp) lv_disp_set_bg_opa(g_disp1, LV_OPA_TRANSP);
-    int W = g_fb_w, H = g_fb_h;
+    int W = lv_disp_get_hor_res(g_disp1), H = lv_disp_get_ver_res(g_disp1); /* logical size */
 
     if(id == 0 || id == 2) {
         /* opaque + translucent rounded rectangles, gradient, border, shadow */

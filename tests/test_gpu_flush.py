@@ -136,3 +136,22 @@ def test_blend_flush_unfused_shapes(gpu, oracle):
         got = to_np(out, np.uint16).reshape(N, -1)
         for f in range(N):
             assert np.array_equal(got[f], oracle.flush_frame(exp_dst[f], W, H, 1, 0))
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_rotate_against_lvgl_own_sw_rotate(gpu, swap):
+    """Whole frames rotated by LVGL's own drv.sw_rotate (golden, recorded from the real library): the GPU rotation
+    with the rotation value lvgpu_rotation_for_lvgl_sw_rotate() names must give the same panel image."""
+    import os
+    from vvc_amd import _lib
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lvgl_sw_rotate_swap%d.npz" % swap))
+    for LW, LH in ((480, 320), (320, 480), (200, 96)):
+        logical = z["logical_%dx%d" % (LW, LH)]
+        d = to_dev(np.repeat(logical[None], 3, axis=0))
+        for lv_rot in (1, 2, 3):
+            mine = _lib.lib().lvgpu_rotation_for_lvgl_sw_rotate(lv_rot)
+            assert mine == {1: 3, 2: 2, 3: 1}[lv_rot]
+            out = to_np(gpu.flush_rotate(d, mine), np.uint16).reshape(3, -1)
+            lvgl = z["lv_rot%d_%dx%d" % (lv_rot, LW, LH)].ravel()
+            for f in range(3):
+                assert np.array_equal(out[f], lvgl), (LW, LH, lv_rot)

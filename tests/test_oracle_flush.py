@@ -50,3 +50,23 @@ def test_mapping_formulas(oracle):
     assert np.array_equal(oracle.flush_frame(frame, W, H, 1).reshape(W, H), img[::-1, :].T)   # out[x][H-1-y]
     assert np.array_equal(oracle.flush_frame(frame, W, H, 3).reshape(W, H), img[:, ::-1].T)   # out[W-1-x][y]
     assert np.array_equal(oracle.flush_frame(frame, W, H, 0, 1), frame.byteswap())
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_rotation_mappings_against_lvgl_own_sw_rotate(oracle, swap):
+    """The reference's flush callback cannot be compiled here, but LVGL carries its own software rotation
+    (libraries/lvgl/src/core/lv_refr.c:1084-1265) for the same three permutations, with the two quarter turns named the
+    other way round.  Golden frames: a widget scene rendered un-rotated and what LVGL itself flushed with
+    drv.sw_rotate for drv.rotated = 90/180/270 (oracle/gen_golden_scenes.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lvgl_sw_rotate_swap%d.npz" % swap))
+    for LW, LH in ((480, 320), (320, 480), (200, 96)):
+        logical = z["logical_%dx%d" % (LW, LH)]
+        assert logical.shape == (LH, LW) and len(np.unique(logical)) > 20
+        for lv_rot, mine in ((1, 3), (2, 2), (3, 1)):
+            lvgl = z["lv_rot%d_%dx%d" % (lv_rot, LW, LH)]
+            got = oracle.flush_frame(logical, LW, LH, mine, 0)
+            assert np.array_equal(got, lvgl.ravel()), (LW, LH, lv_rot)
+            other = oracle.flush_frame(logical, LW, LH, lv_rot, 0)
+            if lv_rot != 2:
+                assert not np.array_equal(other, lvgl.ravel()), "the two namings must differ"

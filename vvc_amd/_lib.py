@@ -101,6 +101,8 @@ def lib():
         "lvgpu_blend_batch": (C.c_int, [C.POINTER(BlendBatch), vp]),
         "lvgpu_flush_rotate_batch": (C.c_int, [C.POINTER(FlushBatch), vp]),
         "lvgpu_blend_flush_batch": (C.c_int, [C.POINTER(BlendFlushBatch), vp]),
+        "lvgpu_flush_chunks": (C.c_int, [C.POINTER(Area), C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                         C.POINTER(FlushChunk), C.c_int32]),
         "lvgpu_blend_list_batch": (C.c_int, [C.POINTER(BlendBatch), C.c_int32, vp]),
         "lvgpu_blend_list_flush_batch": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, vp, C.c_int64,
                                                    C.c_int32, C.c_int32, vp]),
@@ -131,6 +133,12 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+class FlushChunk(C.Structure):
+    """lvgpu_flush_chunk_t"""
+    _fields_ = [("x_start", C.c_int32), ("y_start", C.c_int32), ("x_end", C.c_int32), ("y_end", C.c_int32),
+                ("offset_px", C.c_int64), ("n_px", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LvgpuError(RuntimeError):

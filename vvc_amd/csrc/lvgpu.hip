@@ -825,6 +825,71 @@ int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_b
     return run_list(geom, items, n_items, true, out, out_frame_stride, rotation, swap_bytes, (hipStream_t)stream);
 }
 
+int lvgpu_flush_chunks(const lvgpu_area_t * area, int32_t hor_res, int32_t ver_res, int32_t rot, uint32_t trans_size,
+                       lvgpu_flush_chunk_t * out, int32_t max_chunks)
+{
+    if(area == nullptr) return fail(LVGPU_ERR_ARG, "area is NULL");
+    if(rot < LVGPU_ROT_NONE || rot > LVGPU_ROT_270) return fail(LVGPU_ERR_ARG, "bad rotation %d", rot);
+    const int x_start = area->x1, x_end = area->x2, y_start = area->y1, y_end = area->y2;
+    const int W = x_end - x_start + 1, H = y_end - y_start + 1;
+    if(W <= 0 || H <= 0) return fail(LVGPU_ERR_ARG, "empty area");
+    const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
+    const int step = transposing ? (int)(trans_size / (uint32_t)H) : (int)(trans_size / (uint32_t)W);
+    if(step <= 0) return fail(LVGPU_ERR_ARG, "trans_size %u is smaller than one line of the flushed area", trans_size);
+    const int span = transposing ? W : H;  // chunks advance along x (rotated) or y
+    const int line = transposing ? H : W;  // pixels per advanced line in the panel image
+    const int max_step = step > span ? span : step;
+    int n_chunks = 0;
+    for(int done = 0; done < span; done += max_step, n_chunks++) {
+        if(out == nullptr || n_chunks >= max_chunks) continue;
+        const int n = span - done > max_step ? max_step : span - done;
+        lvgpu_flush_chunk_t & c = out[n_chunks];
+        int xd0, yd0, xd1, yd1;
+        switch(rot) {
+            case LVGPU_ROT_90: {  // columns from the left edge (:482-484, :506-509)
+                const int xs = x_start + done, xe = xs + n - 1;
+                xd0 = ver_res - y_end - 1;
+                xd1 = ver_res - y_start - 1;
+                yd0 = xs;
+                yd1 = xe;
+                break;
+            }
+            case LVGPU_ROT_270: {  // columns from the right edge (:485-487, :517-520)
+                const int xe = x_end - done, xs = xe - n + 1;
+                xd0 = y_start;
+                xd1 = y_end;
+                yd0 = hor_res - xe - 1;
+                yd1 = hor_res - xs - 1;
+                break;
+            }
+            case LVGPU_ROT_180: {  // rows from the bottom edge (:491-494, :528-531)
+                const int ye = y_end - done, ys = ye - n + 1;
+                xd0 = hor_res - x_end - 1;
+                xd1 = hor_res - x_start - 1;
+                yd0 = ver_res - ye - 1;
+                yd1 = ver_res - ys - 1;
+                break;
+            }
+            default: {  // rows from the top edge (:488-490, :539-542)
+                const int ys = y_start + done, ye = ys + n - 1;
+                xd0 = x_start;
+                xd1 = x_end;
+                yd0 = ys;
+                yd1 = ye;
+                break;
+            }
+        }
+        c.x_start = xd0;
+        c.y_start = yd0;
+        c.x_end = xd1 + 1;
+        c.y_end = yd1 + 1;
+        c.offset_px = (int64_t)done * line;
+        c.n_px = n * line;
+        c.reserved = 0;
+    }
+    return n_chunks;
+}
+
 int lvgpu_color_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap, void * stream)
 {
     if(n == 0) return LVGPU_OK;

@@ -449,7 +449,8 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         fprintf(stderr, "lvgpu_flush_cb: drv->user_data must point to a lvgpu_flush_cfg_t with a draw_bitmap sink\n");
         abort();
     }
-    if(drv->draw_ctx) lvgpu_wait_for_finish(drv->draw_ctx);  // deferred mode: the queued blends are drawn now
+    // deferred mode: the queued blends are drawn now (only a context this library initialised carries a queue)
+    if(drv->draw_ctx && drv->draw_ctx_init == lvgpu_draw_ctx_init) lvgpu_wait_for_finish(drv->draw_ctx);
     const int x_start = area->x1, x_end = area->x2, y_start = area->y1, y_end = area->y2;
     const int W = x_end - x_start + 1, H = y_end - y_start + 1;
     const int rot = cfg->sw_rotate;
@@ -504,55 +505,32 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
 
     // Hand the panel image to the sink in the reference's transport chunks (src/lv_port.c:466-566): same
     // rectangles, same order.  Each chunk is a contiguous slice of the rotated image.
-    const int span = transposing ? W : H;          // chunks advance along x (rotated) or y
-    const int line = transposing ? H : W;          // pixels per advanced line in the panel image
-    const int max_step = step > span ? span : step;
-    bool first = true;
-    for(int done = 0; done < span; done += max_step) {
-        const int n = span - done > max_step ? max_step : span - done;
-        int xd0, yd0, xd1, yd1;
-        switch(rot) {
-            case LVGPU_ROT_90: {  // columns from the left edge (:482-484, :506-509)
-                const int xs = x_start + done, xe = xs + n - 1;
-                xd0 = drv->ver_res - y_end - 1;
-                xd1 = drv->ver_res - y_start - 1;
-                yd0 = xs;
-                yd1 = xe;
-                break;
-            }
-            case LVGPU_ROT_270: {  // columns from the right edge (:485-487, :517-520)
-                const int xe = x_end - done, xs = xe - n + 1;
-                xd0 = y_start;
-                xd1 = y_end;
-                yd0 = drv->hor_res - xe - 1;
-                yd1 = drv->hor_res - xs - 1;
-                break;
-            }
-            case LVGPU_ROT_180: {  // rows from the bottom edge (:491-494, :528-531)
-                const int ye = y_end - done, ys = ye - n + 1;
-                xd0 = drv->hor_res - x_end - 1;
-                xd1 = drv->hor_res - x_start - 1;
-                yd0 = drv->ver_res - ye - 1;
-                yd1 = drv->ver_res - ys - 1;
-                break;
-            }
-            default: {  // rows from the top edge (:488-490, :539-542)
-                const int ys = y_start + done, ye = ys + n - 1;
-                xd0 = x_start;
-                xd1 = x_end;
-                yd0 = ys;
-                yd1 = ye;
-                break;
-            }
-        }
-        if(first) {
-            if(cfg->draw_wait) cfg->draw_wait(cfg->user);  // :548-551
-            first = false;
-        }
-        cfg->draw_bitmap(cfg->user, xd0, yd0, xd1 + 1, yd1 + 1, panel + (size_t)done * line);
+    const lvgpu_area_t fa{(int16_t)x_start, (int16_t)y_start, (int16_t)x_end, (int16_t)y_end};
+    const int n_chunks = lvgpu_flush_chunks(&fa, drv->hor_res, drv->ver_res, rot, cfg->trans_size, nullptr, 0);
+    static thread_local std::vector<lvgpu_flush_chunk_t> chunks;
+    chunks.resize(n_chunks > 0 ? (size_t)n_chunks : 0);
+    if(n_chunks <= 0 || lvgpu_flush_chunks(&fa, drv->hor_res, drv->ver_res, rot, cfg->trans_size, chunks.data(), n_chunks) != n_chunks) {
+        fprintf(stderr, "lvgpu_flush_cb: %s -- aborting\n", lvgpu_last_error());
+        abort();
+    }
+    for(int i = 0; i < n_chunks; i++) {
+        if(i == 0 && cfg->draw_wait) cfg->draw_wait(cfg->user);  // :548-551
+        const lvgpu_flush_chunk_t & c = chunks[(size_t)i];
+        cfg->draw_bitmap(cfg->user, c.x_start, c.y_start, c.x_end, c.y_end, panel + c.offset_px);
     }
     g_flush_gpu++;
     flush_ready(drv);  // :571
+}
+
+int lvgpu_rotation_for_lvgl_sw_rotate(int lv_disp_rot)
+{
+    switch(lv_disp_rot) {
+        case 0: return LVGPU_ROT_NONE;
+        case 1: return LVGPU_ROT_270;
+        case 2: return LVGPU_ROT_180;
+        case 3: return LVGPU_ROT_90;
+        default: return -1;
+    }
 }
 
 void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out)

@@ -214,6 +214,24 @@ def blend_list_flush(ctx, dscs, rotation, swap_bytes=0, clips=None, out=None, st
     return out
 
 
+def flush_chunks(area, hor_res, ver_res, rotation, trans_size):
+    """The transport chunks of the reference's flush callback for `area` (src/lv_port.c:466-566) as
+    [(x_start, y_start, x_end, y_end, offset_px, n_px)]: panel rectangle (end exclusive) and the slice of the area's
+    panel image that goes there.  Host arithmetic, no GPU needed."""
+    a = Area.of(area)
+    L = _lib.lib()
+    n = check_count(L.lvgpu_flush_chunks(C.byref(a), hor_res, ver_res, rotation, trans_size, None, 0))
+    arr = (_lib.FlushChunk * max(n, 1))()
+    check_count(L.lvgpu_flush_chunks(C.byref(a), hor_res, ver_res, rotation, trans_size, arr, n))
+    return [(c.x_start, c.y_start, c.x_end, c.y_end, c.offset_px, c.n_px) for c in arr[:n]]
+
+
+def check_count(rc):
+    if rc < 0:
+        raise LvgpuError(rc, _lib.lib().lvgpu_last_error().decode())
+    return rc
+
+
 class BlendList:
     """A display list marshalled once and replayed many times (the descriptors, their sources and masks and ctx.buf
     must stay alive and in place)."""
