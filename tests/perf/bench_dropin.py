@@ -1,6 +1,6 @@
 """Live LVGL (oracle/_ref, the real library) rendering one widget scene per refresh: LVGL's software blend, the GPU
 plug-in in immediate mode (one staged blend per call) and in deferred mode (one display list per flush).
-Run on the GPU box:  python tools/bench_dropin.py"""
+Run on the GPU box:  python tests/perf/bench_dropin.py"""
 import ctypes as C
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import lvref_py as O  # noqa: E402
 from vvc_amd import _lib, lvgpu  # noqa: E402
 

@@ -3,7 +3,7 @@
 run in the build container.  Frames are streamed through a working set far larger than the caches.  The flush
 rotate is the restated lv_port.c loop nest (the reference file itself cannot be compiled here).
 
-    python tools/cpu_baseline_lvgl.py [n_procs]
+    python tests/perf/cpu_baseline_lvgl.py [n_procs]
 """
 import ctypes as C
 import multiprocessing as mp
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import lvref_py as O  # noqa: E402
 
