@@ -199,6 +199,31 @@ int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_b
                                  void * out, int64_t out_frame_stride, int32_t rotation, int32_t swap_bytes, void * stream);
 
 /*
+ * What a display list would cost, without drawing anything (host arithmetic only; no device memory is touched, the
+ * pointers in the descriptors are only compared and checked for alignment).  geom may be NULL (= items[0]); flush != 0
+ * describes lvgpu_blend_list_flush_batch with `rotation`, else lvgpu_blend_list_batch.
+ *   tiles / tiles_selected / tiles_overwritten : 64x64 tiles of the buffer; visited; never read because an opaque item
+ *                                                covers them
+ *   items_listed / items_standalone / items_noop: drawn by the tile pass; run through the single-descriptor path in
+ *                                                their place; dropped by the gates of lv_draw_sw_blend (opa, clip, mask_res)
+ *   launches                                   : kernel launches in total
+ *   item_steps / batch_steps                   : steps of the tile lists (one item over a large region / one batch of chunks)
+ *   chunks_full / chunks_partial               : 8-pixel pieces in the batches
+ *   px_item_steps + px_chunks + px_culled      : == the clipped pixels of all listed items; px_culled is what per-tile
+ *                                                occlusion culling removed
+ */
+typedef struct {
+    int32_t tiles, tiles_selected, tiles_overwritten;
+    int32_t items_listed, items_standalone, items_noop;
+    int32_t launches, flush_fused;
+    int64_t item_steps, batch_steps, chunks_full, chunks_partial;
+    int64_t px_item_steps, px_chunks, px_culled;
+} lvgpu_list_plan_t;
+
+int lvgpu_blend_list_plan(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, int32_t flush,
+                          int32_t rotation, lvgpu_list_plan_t * plan);
+
+/*
  * The transport chunks of the reference's flush callback (src/lv_port.c:466-566): the flushed area is cut into pieces of
  * at most trans_size pixels -- whole source columns for 90/270 degrees (:482-487, :500-521), whole rows otherwise
  * (:488-494, :522-543) -- and each piece is sent to the panel as one rectangle.  Every piece is a contiguous slice of

@@ -205,3 +205,90 @@ def test_flush_chunks_match_the_restated_flush_callback(oracle):
         lvgpu.flush_chunks((0, 0, 99, 9), 100, 10, 1, 5)      # trans_size below one line
     with pytest.raises(lvgpu.LvgpuError):
         lvgpu.flush_chunks((0, 0, 99, 9), 100, 10, 7, 500)    # bad rotation
+
+
+def _plan_of_scene(path, W=480, H=320, flush=1):
+    """lvgpu_blend_list_plan on a golden display list; the pointers are placeholders (the plan never touches memory)."""
+    from util import load_scene
+    from vvc_amd import _lib
+    fb, items = load_scene(path)
+    arr = (_lib.BlendBatch * len(items))()
+    total_px = 0
+    for i, it in enumerate(items):
+        b = arr[i]
+        b.dst = 0x10000
+        b.dst_frame_stride = W * H
+        b.buf_area = _lib.Area(0, 0, W - 1, H - 1)
+        b.clip_area = b.blend_area = b.mask_area = _lib.Area(*it["area"])
+        b.n_frames = 4
+        b.src_format = 0 if it["src"] is None else 1
+        b.src = None if it["src"] is None else 0x20000
+        b.mask = None if it["mask"] is None else 0x30000
+        b.mask_res = 2
+        b.color, b.opa, b.blend_mode, b.color_16_swap = it["color"], it["opa"], it["blend_mode"], 1
+        if it["opa"] > 2:
+            total_px += (it["area"][2] - it["area"][0] + 1) * (it["area"][3] - it["area"][1] + 1)
+    plan = _lib.ListPlan()
+    rc = _lib.lib().lvgpu_blend_list_plan(None, arr, len(items), flush, 1, C.byref(plan))
+    assert rc == 0, _lib.lib().lvgpu_last_error()
+    return plan.as_dict(), len(items), total_px
+
+
+def test_list_plan_of_recorded_lvgl_scenes():
+    """Host side of the display lists (binning, batching, occlusion culling) on the golden LVGL recordings, no GPU:
+    every clipped pixel of every listed item is accounted for exactly once, the hundreds of one-row descriptors
+    collapse into few steps per tile, and the opaque screen background makes every tile write-only."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, n_exp in (("scene0_f0_swap1.npz", 762), ("scene1_f0_swap1.npz", 888), ("scene2_f0_swap1.npz", 1649)):
+        p, n, total_px = _plan_of_scene(os.path.join(gold, name))
+        assert n == n_exp
+        assert p["items_listed"] + p["items_standalone"] + p["items_noop"] == n
+        assert p["items_standalone"] == 0 and p["launches"] == 1 and p["flush_fused"] == 1
+        assert p["tiles"] == 8 * 5 and p["tiles_selected"] == 40 and p["tiles_overwritten"] == 40
+        assert p["px_item_steps"] + p["px_chunks"] + p["px_culled"] == total_px
+        assert p["px_culled"] == 0  # nothing but the background covers a whole tile opaquely in these scenes
+        steps = p["item_steps"] + p["batch_steps"]
+        assert steps < n // 3, "one-row descriptors must be batched (%d steps for %d items)" % (steps, n)
+        assert p["chunks_full"] > 4 * p["chunks_partial"]
+    # without the flush only tiles with work are visited (all of them here: the background touches every tile)
+    p2, _, _ = _plan_of_scene(os.path.join(gold, "scene0_f0_swap1.npz"), flush=0)
+    assert p2["flush_fused"] == 0 and p2["launches"] == 1 and p2["tiles_selected"] == 40
+
+
+def test_list_plan_culling_and_fallbacks():
+    from vvc_amd import _lib
+
+    def mk(area, color=1, opa=255, W=128, H=128, dst=0x10000, clip=None):
+        b = _lib.BlendBatch()
+        b.dst, b.dst_frame_stride, b.n_frames = dst, W * H, 2
+        b.buf_area = _lib.Area(0, 0, W - 1, H - 1)
+        b.clip_area = b.blend_area = b.mask_area = _lib.Area(*area)
+        if clip is not None:
+            b.clip_area = _lib.Area(*clip)
+        b.color, b.opa, b.color_16_swap, b.mask_res = color, opa, 1, 2
+        return b
+
+    def plan(items, flush=0):
+        arr = (_lib.BlendBatch * len(items))(*items)
+        p = _lib.ListPlan()
+        assert _lib.lib().lvgpu_blend_list_plan(None, arr, len(items), flush, 0, C.byref(p)) == 0
+        return p.as_dict()
+
+    full = (0, 0, 127, 127)
+    # three opaque full-screen fills: only the last survives in every tile
+    p = plan([mk(full, 1), mk(full, 2), mk(full, 3)])
+    assert p["px_culled"] == 2 * 128 * 128 and p["px_item_steps"] == 128 * 128 and p["tiles_overwritten"] == 4
+    # a translucent fill whose value on black depends on scan order leaves the tile pass: 3 launches
+    # (stored colour 0x00F0 = native red 30 under LV_COLOR_16_SWAP 1; opa 135: lv_color_mix gives 15 on black, the
+    # premultiplied formula 16)
+    p = plan([mk(full, 1), mk((3, 3, 40, 40), 0x00F0, opa=135), mk((0, 0, 9, 0), 5)])
+    assert (p["items_listed"], p["items_standalone"], p["launches"]) == (2, 1, 3)
+    # an unaligned buffer cannot use the tile pass at all: every item on its own
+    p = plan([mk(full, 1, dst=0x10002), mk((1, 1, 5, 5), 2, dst=0x10002)])
+    assert (p["items_listed"], p["items_standalone"], p["launches"]) == (0, 2, 2)
+    # opa <= LV_OPA_MIN and empty clips are dropped
+    p = plan([mk(full, 1, opa=2), mk((200, 200, 210, 210), 1, clip=full)])
+    assert p["items_noop"] == 2 and p["launches"] == 0
+    # a clip that reaches outside the buffer is an error, as in lvgpu_blend_batch
+    arr = (_lib.BlendBatch * 1)(mk((120, 120, 130, 130), 1))
+    assert _lib.lib().lvgpu_blend_list_plan(None, arr, 1, 0, 0, C.byref(_lib.ListPlan())) == -1

@@ -104,6 +104,8 @@ def lib():
         "lvgpu_flush_chunks": (C.c_int, [C.POINTER(Area), C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.POINTER(FlushChunk), C.c_int32]),
         "lvgpu_blend_list_batch": (C.c_int, [C.POINTER(BlendBatch), C.c_int32, vp]),
+        "lvgpu_blend_list_plan": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, C.c_int32, C.c_int32,
+                                            C.POINTER(ListPlan)]),
         "lvgpu_blend_list_flush_batch": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, vp, C.c_int64,
                                                    C.c_int32, C.c_int32, vp]),
         "lvgpu_color_from_rgb888": (C.c_int, [vp, vp, sz, C.c_int, vp]),
@@ -133,6 +135,17 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+class ListPlan(C.Structure):
+    """lvgpu_list_plan_t"""
+    _fields_ = [(n, C.c_int32) for n in ("tiles", "tiles_selected", "tiles_overwritten", "items_listed", "items_standalone",
+                                         "items_noop", "launches", "flush_fused")] + \
+               [(n, C.c_int64) for n in ("item_steps", "batch_steps", "chunks_full", "chunks_partial", "px_item_steps",
+                                         "px_chunks", "px_culled")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class FlushChunk(C.Structure):

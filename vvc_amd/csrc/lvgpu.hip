@@ -490,17 +490,30 @@ uint32_t item_kind(const ListItem & it)
     return list_kind(it.fmt, om, blended) | (it.mask ? 128u : 0u);
 }
 
-// Turn the bins into per-tile step lists (see ListStep / ListChunk in lvgpu_list.hpp) and launch.
-// out != nullptr: also write the panel image of every tile (all tiles are visited).
-int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_frames, int swap, uint16_t * out, long long out_fs,
-                int rot, int swap_out, hipStream_t st)
+// The per-tile step lists of the accumulated items (see ListStep / ListChunk in lvgpu_list.hpp).
+struct ListPlan {
+    std::vector<uint32_t> bin_start, sel;
+    std::vector<uint4> steps;
+    std::vector<uint2> chunks;
+    lvgpu_list_plan_t stats;
+};
+
+inline int popcount8(uint32_t v) { return __builtin_popcount(v & 0xFFu); }
+
+// all_tiles: every tile is visited (the panel image is written from the tiles), otherwise only tiles with work.
+void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
 {
     const uint32_t n_tiles = lb.tiles_x * lb.tiles_y;
-    std::vector<uint32_t> bin_start(n_tiles + 1), sel;
-    std::vector<uint4> steps;
-    std::vector<uint2> chunks, full, part;
+    p.bin_start.assign(n_tiles + 1, 0);
+    p.sel.clear();
+    p.steps.clear();
+    p.chunks.clear();
+    memset(&p.stats, 0, sizeof(p.stats));
+    p.stats.tiles = (int32_t)n_tiles;
+    p.stats.items_listed = (int32_t)lb.items.size();
+    std::vector<uint2> full, part;
     for(uint32_t t = 0; t < n_tiles; t++) {
-        bin_start[t] = (uint32_t)steps.size();
+        p.bin_start[t] = (uint32_t)p.steps.size();
         bool ow = false;
         const size_t first = lb.first_live(t, &ow);
         const int tx0 = (int)(t % lb.tiles_x) * LT, ty0 = (int)(t / lb.tiles_x) * LT;
@@ -508,22 +521,32 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
         uint64_t occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per group column: rows of the tile the current batch touches
         auto flush = [&]() {
             if(full.empty() && part.empty()) return;
-            steps.push_back(make_uint4(kind & 0x7Fu, (uint32_t)chunks.size(), (uint32_t)full.size(), (uint32_t)part.size()));
-            chunks.insert(chunks.end(), full.begin(), full.end());
-            chunks.insert(chunks.end(), part.begin(), part.end());
+            p.steps.push_back(make_uint4(kind & 0x7Fu, (uint32_t)p.chunks.size(), (uint32_t)full.size(), (uint32_t)part.size()));
+            p.chunks.insert(p.chunks.end(), full.begin(), full.end());
+            p.chunks.insert(p.chunks.end(), part.begin(), part.end());
+            p.stats.batch_steps++;
+            p.stats.chunks_full += (int64_t)full.size();
+            p.stats.chunks_partial += (int64_t)part.size();
             full.clear();
             part.clear();
             for(auto & o : occ) o = 0;
         };
-        for(size_t i = first; i < lb.bins[t].size(); i++) {
+        for(size_t i = 0; i < lb.bins[t].size(); i++) {
             const uint32_t id = lb.bins[t][i];
             const ListItem & it = lb.items[id];
             const int x1 = std::max(it.x1, tx0) - tx0, x2 = std::min(it.x2, tx0 + LT - 1) - tx0;
             const int y1 = std::max(it.y1, ty0) - ty0, y2 = std::min(it.y2, ty0 + LT - 1) - ty0;
             if(x2 < x1 || y2 < y1) continue;
-            if((x2 - x1 + 1) * (y2 - y1 + 1) >= LIST_BIG_REGION) {
+            const int region_px = (x2 - x1 + 1) * (y2 - y1 + 1);
+            if(i < first) {  // hidden by a later item that overwrites the whole tile
+                p.stats.px_culled += region_px;
+                continue;
+            }
+            if(region_px >= LIST_BIG_REGION) {
                 flush();
-                steps.push_back(make_uint4(LIST_STEP_ITEM | id, 0, 0, 0));
+                p.steps.push_back(make_uint4(LIST_STEP_ITEM | id, 0, 0, 0));
+                p.stats.item_steps++;
+                p.stats.px_item_steps += region_px;
                 continue;
             }
             const uint32_t k = item_kind(it);
@@ -538,12 +561,29 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
                 const uint32_t pxmask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
                 for(int y = y1; y <= y2; y++)
                     (pxmask == 0xFFu ? full : part).push_back(make_uint2(id, (uint32_t)y | ((uint32_t)g << 6) | (pxmask << 9)));
+                p.stats.px_chunks += (int64_t)popcount8(pxmask) * (y2 - y1 + 1);
             }
         }
         flush();
-        if(out || steps.size() > bin_start[t]) sel.push_back(t | (ow ? 0x80000000u : 0u));
+        if(all_tiles || p.steps.size() > p.bin_start[t]) {
+            p.sel.push_back(t | (ow ? 0x80000000u : 0u));
+            p.stats.tiles_selected++;
+            if(ow) p.stats.tiles_overwritten++;
+        }
     }
-    bin_start[n_tiles] = (uint32_t)steps.size();
+    p.bin_start[n_tiles] = (uint32_t)p.steps.size();
+}
+
+// Launch the accumulated items.  out != nullptr: also write the panel image of every tile.
+int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_frames, int swap, uint16_t * out, long long out_fs,
+                int rot, int swap_out, hipStream_t st)
+{
+    static thread_local ListPlan plan;  // keeps its capacity between calls
+    build_plan(lb, out != nullptr, plan);
+    const std::vector<uint32_t> & bin_start = plan.bin_start;
+    const std::vector<uint32_t> & sel = plan.sel;
+    const std::vector<uint4> & steps = plan.steps;
+    const std::vector<uint2> & chunks = plan.chunks;
     if(sel.empty()) {
         lb.clear();
         return LVGPU_OK;
@@ -601,9 +641,27 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     return LVGPU_OK;
 }
 
-int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int n_items, bool flush, void * out_v,
-             long long out_fs, int rot, int swap_out, hipStream_t st)
+void add_stats(lvgpu_list_plan_t & acc, const lvgpu_list_plan_t & s)
 {
+    acc.tiles = s.tiles;
+    acc.tiles_selected += s.tiles_selected;
+    acc.tiles_overwritten += s.tiles_overwritten;
+    acc.items_listed += s.items_listed;
+    acc.launches++;
+    acc.item_steps += s.item_steps;
+    acc.batch_steps += s.batch_steps;
+    acc.chunks_full += s.chunks_full;
+    acc.chunks_partial += s.chunks_partial;
+    acc.px_item_steps += s.px_item_steps;
+    acc.px_chunks += s.px_chunks;
+    acc.px_culled += s.px_culled;
+}
+
+// plan != nullptr: nothing is launched; the work the call would do is described in *plan.
+int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int n_items, bool flush, void * out_v,
+             long long out_fs, int rot, int swap_out, hipStream_t st, lvgpu_list_plan_t * plan = nullptr)
+{
+    if(plan) memset(plan, 0, sizeof(*plan));
     g_last_kernel = "";
     if(n_items < 0) return fail(LVGPU_ERR_ARG, "n_items < 0");
     if(n_items > 0 && items == nullptr) return fail(LVGPU_ERR_ARG, "items is NULL");
@@ -646,6 +704,37 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     ListBuilder lb(W, H);
     int rc;
     bool used_list = false;
+    if(plan) {  // describe, do not draw
+        ListPlan p;
+        auto close_segment = [&](bool all_tiles) {
+            if(lb.items.empty() && !all_tiles) return;
+            build_plan(lb, all_tiles, p);
+            add_stats(*plan, p.stats);
+            lb.clear();
+        };
+        for(int i = 0; i < n_items; i++) {
+            if(res[i] != R_WORK) {
+                plan->items_noop++;
+                continue;
+            }
+            if(tiles_ok && !needs_scan_order(ra[i])) {
+                lb.add(ra[i], items[i].src_format, areas[i], geom->buf_area);
+                continue;
+            }
+            close_segment(false);
+            plan->items_standalone++;
+            plan->launches++;
+        }
+        if(fuse_out && !lb.items.empty()) {
+            close_segment(true);
+            plan->flush_fused = 1;
+        }
+        else {
+            close_segment(false);
+            if(flush) plan->launches++;
+        }
+        return LVGPU_OK;
+    }
     for(int i = 0; i < n_items; i++) {
         if(res[i] != R_WORK) continue;
         if(tiles_ok && !needs_scan_order(ra[i])) {
@@ -817,6 +906,15 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
 int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream)
 {
     return run_list(n_items > 0 ? items : nullptr, items, n_items, false, nullptr, 0, 0, 0, (hipStream_t)stream);
+}
+
+int lvgpu_blend_list_plan(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, int32_t flush,
+                          int32_t rotation, lvgpu_list_plan_t * plan)
+{
+    if(plan == nullptr) return fail(LVGPU_ERR_ARG, "plan is NULL");
+    // the output pointer is only inspected for its alignment: a fused flush is assumed possible
+    return run_list(geom ? geom : (n_items > 0 ? items : nullptr), items, n_items, flush != 0, flush ? (void *)(uintptr_t)256 : nullptr, 0,
+                    rotation, 0, nullptr, plan);
 }
 
 int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, void * out,

@@ -245,6 +245,12 @@ class BlendList:
     def run(self, stream=None):
         check(_lib.lib().lvgpu_blend_list_batch(self.arr, self.n, _stream(stream)))
 
+    def plan(self, flush=False, rotation=0):
+        """What replaying the list costs (lvgpu_list_plan_t as a dict); nothing is drawn."""
+        p = _lib.ListPlan()
+        check(_lib.lib().lvgpu_blend_list_plan(C.byref(self.geom), self.arr, self.n, 1 if flush else 0, rotation, C.byref(p)))
+        return p.as_dict()
+
     def run_flush(self, rotation, swap_bytes=0, out=None, stream=None):
         n, h, w = self.ctx.buf.shape[:3]
         if out is None:
