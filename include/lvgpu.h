@@ -187,9 +187,9 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * dsc, void * stream
  * areas, sources, masks, colours, opacities and blend modes are per item.  src/mask buffers must not overlap dst.
  * The draw buffers are read once and written once per list (tiles of the buffer stay on chip while the tile's items
  * are applied), except that an item which needs a whole-area pre-pass (a translucent unmasked fill whose result on
- * black depends on scan order, lv_draw_sw_blend.c:262-283) or a shape the tile kernel does not take (width not a
- * multiple of 8 pixels, unaligned dst, ARGB8565 dst) is run through the lvgpu_blend_batch path in its place in the
- * order.  items is host memory and may be released when the call returns.
+ * black depends on scan order, lv_draw_sw_blend.c:262-283) or a shape the tile kernels do not take (width not a
+ * multiple of 8 pixels -- 16 for an ARGB8565 destination --, unaligned dst) is run through the lvgpu_blend_batch
+ * path in its place in the order.  items is host memory and may be released when the call returns.
  */
 int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream);
 

@@ -19,6 +19,8 @@ def addr(fn):
 
 def main():
     W, H, scene, reps = 480, 320, 2, 20
+    flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # ref_scene_display flags: 1 = AA off, 2 = transparent screen
+    bpp = 3 if flags & 2 else 2
     lvgpu.init(0)
     R = O.ref(1)
     L = _lib.lib()
@@ -29,10 +31,10 @@ def main():
         L.lvgpu_lvgl_set_deferred(1 if mode == "gpu_deferred" else 0)
         R.ref_scene_set_pre_flush(addr(L.lvgpu_wait_for_finish) if mode == "gpu_deferred" else None)
         if mode == "lvgl_sw":
-            R.ref_scene_display(W, H, None, None, 0, None, None, 1, 0)
+            R.ref_scene_display(W, H, None, None, 0, None, None, 1, flags)
         else:
             R.ref_scene_display(W, H, addr(L.lvgpu_draw_ctx_init), addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
-                                None, None, 1, 0)
+                                None, None, 1, flags)
         R.ref_scene_build(scene)
         R.ref_scene_refresh()
         t0 = time.perf_counter()
@@ -40,8 +42,8 @@ def main():
             R.ref_scene_build(scene)   # invalidates the screen again
             R.ref_scene_refresh()
         dt = (time.perf_counter() - t0) / reps
-        frames[mode] = np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint16)), shape=(H * W,)).copy()
-        print("%-14s %8.2f ms per refresh of scene %d (%dx%d)" % (mode, dt * 1e3, scene, W, H), flush=True)
+        frames[mode] = np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint8)), shape=(H * W * bpp,)).copy()
+        print("%-14s %8.2f ms per refresh of scene %d (%dx%d, flags %d)" % (mode, dt * 1e3, scene, W, H, flags), flush=True)
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
     R.ref_scene_set_pre_flush(None)
     print("identical frames:", all(np.array_equal(frames["lvgl_sw"], v) for v in frames.values()))

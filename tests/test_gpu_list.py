@@ -205,3 +205,35 @@ def test_recorded_lvgl_scene_replayed_as_one_list(gpu, oracle, path):
     o = to_np(out, np.uint16).reshape(N, -1)
     for f in range(N):
         assert np.array_equal(o[f], exp_out)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+@pytest.mark.parametrize("W,H,N", [(128, 96, 3), (480, 320, 2), (80, 50, 2), (72, 40, 2)])
+def test_list_argb8565_destination(gpu, oracle, swap, W, H, N):
+    """Display lists into the 3-byte draw buffer of a transparent screen (fill_argb / map_argb semantics, incl. the
+    mask-row quirk and the blend modes); W = 72 is not a multiple of 16 and takes the per-descriptor path."""
+    rng = np.random.default_rng(600 + swap + W)
+    area = (0, 0, W - 1, H - 1)
+    for scene in range(3):
+        dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+        dst[..., 2] = rand_mask(rng, (N, H, W))
+        items = []
+        while len(items) < 50:
+            it = _rand_item(rng, W, H, N, False)
+            if it["fmt"] in (0, 1):
+                items.append(it)
+        if scene == 0:  # an opaque background first: every tile is written without being read
+            items[0] = dict(ba=area, clip=area, opa=255, color=0x4321, src=None, mask=None, mode=0, fmt=0, mask_res=2)
+        exp = dst.copy()
+        for it in items:
+            for f in range(N):
+                oracle.blend(exp[f], area, it["clip"], it["ba"], src=None if it["src"] is None else it["src"][f],
+                             color=it["color"], mask=None if it["mask"] is None else it["mask"][f], mask_res=it["mask_res"],
+                             opa=it["opa"], blend_mode=it["mode"], swap=swap, screen_transp=1)
+        d = to_dev(dst)
+        ctx = gpu.DrawCtx(d, area, area, color_16_swap=swap, screen_transp=1)
+        dscs, clips, keep = _gpu_items(gpu, items)
+        gpu.blend_list(ctx, dscs, clips)
+        got = to_np(d, np.uint8)
+        assert np.array_equal(got, exp), "scene %d: %d bytes differ" % (scene, int((got != exp).sum()))
+        assert gpu.last_kernel() == ("k_blend_list" if W % 16 == 0 else "k_blend_argb_dst")

@@ -375,7 +375,11 @@ struct ListBuilder {
     uint32_t tiles_x, tiles_y;
     std::vector<ListItem> items;
     std::vector<std::vector<uint32_t>> bins;
-    ListBuilder(int w, int h) : W(w), H(h), tiles_x((w + LT - 1) / LT), tiles_y((h + LT - 1) / LT), bins((size_t)tiles_x * tiles_y) {}
+    bool argb;  // ARGB8565 destination
+    ListBuilder(int w, int h, bool argb_dst)
+        : W(w), H(h), tiles_x((w + LT - 1) / LT), tiles_y((h + LT - 1) / LT), bins((size_t)tiles_x * tiles_y), argb(argb_dst)
+    {
+    }
     void add(const BlendArgs & a, int fmt, const lvgpu_area_t & area, const lvgpu_area_t & buf)
     {
         ListItem it;
@@ -397,6 +401,13 @@ struct ListBuilder {
         it.fmt = fmt;
         it.swap = a.swap;
         it.pf = a.pf;
+        it.raw_mode = a.raw_mode;
+        it.has_mask = a.has_mask;
+        if(argb) {
+            it.opa = (uint32_t)a.raw_opa;
+            // fill_argb's opaque masked loop reads row y of the area at mask[y*w + x] (lv_draw_sw_blend.c:494-505)
+            if(fmt == SRC_FILL && a.mask && a.raw_opa >= 253) it.mask_stride = a.w;
+        }
         const uint32_t id = (uint32_t)items.size();
         items.push_back(it);
         for(int ty = it.y1 / LT; ty <= it.y2 / LT; ty++)
@@ -406,8 +417,14 @@ struct ListBuilder {
     bool overwrites(uint32_t t, uint32_t id) const
     {
         const ListItem & it = items[id];
-        if(!(it.opa_mode == OM_CONST && it.opa == 255u && it.blend_fn == BF_NORMAL)) return false;
-        if(!(it.fmt == SRC_FILL || it.fmt == SRC_RGB565)) return false;
+        if(argb) {  // colour and alpha are stored whatever the pixel held: fill_argb :465-477, map_argb :768-790
+            const bool blended = it.fmt != SRC_FILL && it.raw_mode >= 1 && it.raw_mode <= 3;
+            if(it.has_mask || it.opa < 253u || blended) return false;
+        }
+        else {
+            if(!(it.opa_mode == OM_CONST && it.opa == 255u && it.blend_fn == BF_NORMAL)) return false;
+            if(!(it.fmt == SRC_FILL || it.fmt == SRC_RGB565)) return false;
+        }
         const int tx = (int)(t % tiles_x), ty = (int)(t / tiles_x);
         const int x1 = tx * LT, y1 = ty * LT, x2 = std::min(x1 + LT, W) - 1, y2 = std::min(y1 + LT, H) - 1;
         return it.x1 <= x1 && it.y1 <= y1 && it.x2 >= x2 && it.y2 >= y2;
@@ -481,8 +498,9 @@ thread_local ListStaging g_stage;
 // list; larger parts are walked by the whole wave on their own.
 constexpr int LIST_BIG_REGION = 512;
 
-uint32_t item_kind(const ListItem & it)
+uint32_t item_kind(const ListItem & it, bool argb)
 {
+    if(argb) return (uint32_t)it.fmt | (it.has_mask ? 128u : 0u);  // every lane reads its own item's parameters
     const bool own_alpha = it.fmt == SRC_ARGB8888 || it.fmt == SRC_RGBA8888 || it.fmt == SRC_ARGB8565;
     const bool blended = it.blend_fn != BF_NORMAL;
     int om = blended ? 7 : it.opa_mode;
@@ -549,7 +567,7 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
                 p.stats.px_item_steps += region_px;
                 continue;
             }
-            const uint32_t k = item_kind(it);
+            const uint32_t k = item_kind(it, lb.argb);
             const uint64_t rows = (y2 - y1 == 63 ? ~0ull : ((1ull << (y2 - y1 + 1)) - 1ull) << y1);
             bool conflict = false;
             for(int g = x1 >> 3; g <= (x2 >> 3); g++) conflict = conflict || (occ[g] & rows) != 0;
@@ -634,7 +652,8 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     a.out_fs = out_fs;
     a.rot = rot;
     a.swap_out = swap_out;
-    hipLaunchKernelGGL(k_blend_list, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
+    if(lb.argb) hipLaunchKernelGGL(k_blend_list_argb, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_blend_list, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(dev, st));
     lb.clear();
@@ -697,11 +716,13 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     uint16_t * dst = reinterpret_cast<uint16_t *>(geom->dst);
     uint16_t * out = reinterpret_cast<uint16_t *>(out_v);
     const bool argb = geom->dst_argb8565 != 0;
-    const bool tiles_ok = !argb && (W % 8) == 0 && aligned(dst, 16) && (geom->dst_frame_stride % 8) == 0;
+    // 16-byte tile rows: 8 pixels of 2 bytes, or 16 pixels of 3 bytes
+    const bool tiles_ok = argb ? (W % 16) == 0 && aligned(dst, 16) && (geom->dst_frame_stride * 3) % 16 == 0
+                               : (W % 8) == 0 && aligned(dst, 16) && (geom->dst_frame_stride % 8) == 0;
     const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
     const bool fuse_out = flush && tiles_ok && aligned(out, 16) && (out_fs % 8) == 0 && (!transposing || (H % 8) == 0);
 
-    ListBuilder lb(W, H);
+    ListBuilder lb(W, H, argb);
     int rc;
     bool used_list = false;
     if(plan) {  // describe, do not draw

@@ -625,6 +625,66 @@ __device__ __forceinline__ void px_mix_with_alpha(uint32_t bg, uint32_t bg_opa, 
     }
 }
 
+// One destination pixel of the ARGB8565 path.  a: anything with raw_opa, raw_mode, has_mask, swap.  fill: no source
+// image.  fg/m: source colour (native) and mask or source alpha; bg/bg_opa: what the pixel holds.  Returns what to
+// store: wo -> the alpha byte becomes `opa`, wc -> the colour becomes `color` (native).
+struct ArgbOut {
+    uint32_t color, opa;
+    bool wc, wo;
+};
+template <class A>
+__device__ __forceinline__ ArgbOut argb_dst_px(const A & a, bool fill, uint32_t fg, uint32_t m, uint32_t bg, uint32_t bg_opa)
+{
+    ArgbOut r = {0u, 0u, false, false};
+    const uint32_t opa = (uint32_t)a.raw_opa;
+    const bool blended = !fill && a.raw_mode >= 1 && a.raw_mode <= 3;
+    uint32_t o;
+    bool plain_store = false;
+    if(!a.has_mask) {
+        if(fill) {
+            o = opa;
+            plain_store = opa >= 253u;           // :465-477 writes colour and opa as they are
+        }
+        else o = opa >= 253u ? 255u : opa;       // :768-819
+    }
+    else if(fill) {
+        if(opa >= 253u) o = m;                   // :494-505
+        else {                                   // :507-528
+            if(m == 0u) return r;
+            o = m == 255u ? opa : (m * opa) >> 8;
+        }
+    }
+    else {
+        if(opa > 253u) o = m;                    // :824-843
+        else {                                   // :846-871
+            if(m == 0u) return r;
+            o = m >= 253u ? opa : (opa * m) >> 8;
+        }
+    }
+    if(plain_store) {
+        r.color = fg;
+        r.opa = opa;
+        r.wc = r.wo = true;
+    }
+    else if(blended) {                           // set_px_argb_blend
+        if(bg_opa <= 2u) return r;
+        if(o <= 2u) r.color = bg;
+        else {
+            uint32_t c = a.raw_mode == 1   ? px_blend_fn<BF_ADDITIVE>(fg, bg, a.swap)
+                         : a.raw_mode == 2 ? px_blend_fn<BF_SUBTRACTIVE>(fg, bg, a.swap)
+                                           : px_blend_fn<BF_MULTIPLY>(fg, bg, a.swap);
+            r.color = o == 255u ? c : px_mix(c, bg, o);
+        }
+        r.wc = true;
+    }
+    else {                                       // set_px_argb
+        px_mix_with_alpha(bg, bg_opa, fg, o, r.color, r.opa);
+        r.wo = true;
+        r.wc = r.opa > 2u;
+    }
+    return r;
+}
+
 template <int SRC>
 __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
 {
@@ -633,8 +693,6 @@ __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
     if(idx >= area) return;
     const uint32_t y = idx / (uint32_t)a.w, x = idx - y * (uint32_t)a.w;
     const bool fill = SRC == SRC_FILL;
-    const uint32_t opa = (uint32_t)a.raw_opa;
-    const bool blended = !fill && a.raw_mode >= 1 && a.raw_mode <= 3;
     for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
         uint8_t * dp = reinterpret_cast<uint8_t *>(a.dst) + ((long long)f * a.dst_fs + (size_t)y * a.dst_stride + x) * 3;
         uint32_t fg = a.color, m = 0;
@@ -657,59 +715,18 @@ __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
         if(a.mask) {
             // fill_argb's "only the mask matters" loop (:494-505) never adds (mask_stride - w) at the end of a row:
             // row y of the area reads mask[y*w + x]
-            const size_t mi = (fill && opa >= 253u) ? (size_t)y * a.w + x : (size_t)y * a.mask_stride + x;
+            const size_t mi = (fill && (uint32_t)a.raw_opa >= 253u) ? (size_t)y * a.w + x : (size_t)y * a.mask_stride + x;
             m = a.mask[(long long)f * a.mask_fs + mi];
-        }
-        uint32_t o;
-        bool plain_store = false;
-        if(!a.has_mask) {
-            if(fill) {
-                o = opa;
-                plain_store = opa >= 253u;           // :465-477 writes colour and opa as they are
-            }
-            else o = opa >= 253u ? 255u : opa;       // :768-819
-        }
-        else if(fill) {
-            if(opa >= 253u) o = m;                   // :494-505
-            else {                                   // :507-528
-                if(m == 0u) continue;
-                o = m == 255u ? opa : (m * opa) >> 8;
-            }
-        }
-        else {
-            if(opa > 253u) o = m;                    // :824-843
-            else {                                   // :846-871
-                if(m == 0u) continue;
-                o = m >= 253u ? opa : (opa * m) >> 8;
-            }
         }
         uint32_t bg = dp[0] | (dp[1] << 8);
         if(a.swap) bg = px_swap16(bg);
-        const uint32_t bg_opa = dp[2];
-        uint32_t res;
-        if(plain_store) {
-            res = fg;
-            dp[2] = (uint8_t)opa;
+        const ArgbOut r = argb_dst_px(a, fill, fg, m, bg, dp[2]);
+        if(r.wo) dp[2] = (uint8_t)r.opa;
+        if(r.wc) {
+            const uint32_t c = a.swap ? px_swap16(r.color) : r.color;
+            dp[0] = (uint8_t)(c & 0xFFu);
+            dp[1] = (uint8_t)(c >> 8);
         }
-        else if(blended) {                           // set_px_argb_blend
-            if(bg_opa <= 2u) continue;
-            if(o <= 2u) res = bg;
-            else {
-                uint32_t c = a.raw_mode == 1   ? px_blend_fn<BF_ADDITIVE>(fg, bg, a.swap)
-                             : a.raw_mode == 2 ? px_blend_fn<BF_SUBTRACTIVE>(fg, bg, a.swap)
-                                               : px_blend_fn<BF_MULTIPLY>(fg, bg, a.swap);
-                res = o == 255u ? c : px_mix(c, bg, o);
-            }
-        }
-        else {                                       // set_px_argb
-            uint32_t ro;
-            px_mix_with_alpha(bg, bg_opa, fg, o, res, ro);
-            dp[2] = (uint8_t)ro;
-            if(ro <= 2u) continue;
-        }
-        if(a.swap) res = px_swap16(res);
-        dp[0] = (uint8_t)(res & 0xFFu);
-        dp[1] = (uint8_t)(res >> 8);
     }
 }
 

@@ -27,6 +27,8 @@ struct ListItem {
     int fmt;               // source format
     int swap;              // LV_COLOR_16_SWAP
     PremultFill pf;        // OM_FILL_PREMULT only (lists hold such fills only when black needs no scan-order cache)
+    int raw_mode;          // ARGB8565 destination: dsc->blend_mode as given (opa then holds dsc->opa as given)
+    int has_mask;          // ARGB8565 destination: a per-pixel alpha exists (mask buffer or source alpha)
 };
 
 struct ListArgs {
@@ -429,6 +431,140 @@ __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
                 store_streaming(out + o, v);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same for an ARGB8565 destination (3 bytes per pixel; the draw buffer of a transparent screen or of a layer
+// with alpha, lv_draw_sw_blend.c:129-133, 177-184).  The tile is 64x64x3 bytes of LDS per wave, every step goes
+// pixel by pixel through argb_dst_px, there is no fused flush (the reference flushes lv_color_t buffers only).
+// Requires W % 16 == 0 so that tile rows start on 16-byte boundaries.
+// ---------------------------------------------------------------------------------------------------------------
+struct ArgbLaneView {
+    int raw_opa, raw_mode, has_mask, swap;
+};
+
+template <int SRC>
+__device__ __forceinline__ void argb_list_px(const ListItem & it, int swap, uint8_t * tile, uint32_t f, int row, int col, int ax,
+                                             int ay)
+{
+    uint32_t fg = it.color, m = 0;
+    list_fetch<SRC>(it, f, ax, ay, fg, m);
+    uint8_t * dp = tile + (row * LT + col) * 3;
+    uint32_t bg = dp[0] | (dp[1] << 8);
+    if(swap) bg = px_swap16(bg);
+    ArgbLaneView v;
+    v.raw_opa = (int)it.opa;
+    v.raw_mode = it.raw_mode;
+    v.has_mask = it.has_mask;
+    v.swap = swap;
+    const ArgbOut r = argb_dst_px(v, SRC == SRC_FILL, fg, m, bg, dp[2]);
+    if(r.wo) dp[2] = (uint8_t)r.opa;
+    if(r.wc) {
+        const uint32_t c = swap ? px_swap16(r.color) : r.color;
+        dp[0] = (uint8_t)(c & 0xFFu);
+        dp[1] = (uint8_t)(c >> 8);
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ void argb_list_item(const ListItem & it, int swap, uint8_t * tile, uint32_t f, const ListRegion & r, int lane)
+{
+    const uint32_t rw = (uint32_t)(r.x2 - r.x1 + 1), n = rw * (uint32_t)(r.y2 - r.y1 + 1);
+    const float inv = 1.0f / (float)rw;
+    for(uint32_t idx = (uint32_t)lane; idx < n; idx += 64) {
+        const uint32_t ly = small_div(idx, inv), lx = idx - ly * rw;
+        const int col = r.x1 + (int)lx, row = r.y1 + (int)ly;
+        argb_list_px<SRC>(it, swap, tile, f, row, col, col + r.ox, row + r.oy);
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ void argb_list_batch(const ListArgs & a, uint8_t * tile, uint32_t f, int tx, int ty, uint32_t first,
+                                                uint32_t n, int lane)
+{
+    const uint2 * ch = a.chunks + first;
+    for(uint32_t base = 0; base < n; base += 64) {
+        const uint32_t idx = base + (uint32_t)lane;
+        if(idx >= n) continue;
+        const uint2 c = ch[idx];
+        const ListItem & it = a.items[c.x];
+        const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
+        const uint32_t pxmask = (c.y >> 9) & 0xFFu;
+        const int ax = tx * LT + g * 8 - it.x1, ay = ty * LT + row - it.y1;
+#pragma unroll
+        for(int j = 0; j < 8; j++)
+            if((pxmask >> j) & 1u) argb_list_px<SRC>(it, a.swap, tile, f, row, g * 8 + j, ax + j, ay);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blend_list_argb(ListArgs a)
+{
+    __shared__ uint4 lds4[4][LT * LT * 3 / 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
+    if(wt >= a.n_sel * a.n_frames) return;
+    const uint32_t f = wt / a.n_sel;
+    const uint32_t sel = a.sel[wt - f * a.n_sel];
+    const uint32_t t = sel & 0x7FFFFFFFu;
+    const bool overwrite = (sel >> 31) != 0;
+    const int ty = (int)(t / a.tiles_x), tx = (int)(t - (uint32_t)ty * a.tiles_x);
+    const int W = a.W, H = a.H;
+    uint8_t * dst = reinterpret_cast<uint8_t *>(a.dst) + (long long)f * a.dst_fs * 3;
+    uint4 * tile4 = lds4[wave];
+    uint8_t * tile = reinterpret_cast<uint8_t *>(tile4);
+    const uint32_t k0 = a.bin_start[t], k1 = a.bin_start[t + 1];
+    // a tile row is 192 bytes = 12 chunks of 16; the tile's part of the frame may be narrower (W % 16 == 0)
+    const int tw = min(LT, W - tx * LT), th = min(LT, H - ty * LT);
+    const int cpr = tw * 3 / 16;               // 16-byte chunks per row inside the frame
+    const int n_chunks = cpr * th;
+    if(!overwrite) {
+        for(int i = lane; i < n_chunks; i += 64) {
+            const int row = i / cpr, c = i - row * cpr;
+            tile4[row * 12 + c] = *reinterpret_cast<const uint4 *>(dst + ((size_t)(ty * LT + row) * W + tx * LT) * 3 + c * 16);
+        }
+    }
+    wave_lds_fence();
+
+    uint4 st_next = k0 < k1 ? a.steps[k0] : make_uint4(0, 0, 0, 0);
+    for(uint32_t k = k0; k < k1; k++) {
+        const uint32_t s_x = __builtin_amdgcn_readfirstlane(st_next.x), s_y = __builtin_amdgcn_readfirstlane(st_next.y);
+        const uint32_t s_n = __builtin_amdgcn_readfirstlane(st_next.z + st_next.w);
+        if(k + 1 < k1) st_next = a.steps[k + 1];
+        if(s_x & LIST_STEP_ITEM) {
+            const ListItem & it = a.items[s_x & ~LIST_STEP_ITEM];
+            ListRegion r;
+            r.x1 = max(it.x1, tx * LT) - tx * LT;
+            r.x2 = min(it.x2, tx * LT + LT - 1) - tx * LT;
+            r.y1 = max(it.y1, ty * LT) - ty * LT;
+            r.y2 = min(it.y2, ty * LT + LT - 1) - ty * LT;
+            if(r.x2 < r.x1 || r.y2 < r.y1) continue;
+            r.ox = tx * LT - it.x1;
+            r.oy = ty * LT - it.y1;
+            switch(it.fmt) {
+                case SRC_FILL: argb_list_item<SRC_FILL>(it, a.swap, tile, f, r, lane); break;
+                case SRC_RGB565: argb_list_item<SRC_RGB565>(it, a.swap, tile, f, r, lane); break;
+                case SRC_ARGB8888: argb_list_item<SRC_ARGB8888>(it, a.swap, tile, f, r, lane); break;
+                case SRC_RGBA8888: argb_list_item<SRC_RGBA8888>(it, a.swap, tile, f, r, lane); break;
+                default: argb_list_item<SRC_ARGB8565>(it, a.swap, tile, f, r, lane); break;
+            }
+        }
+        else {
+            switch(s_x & 7u) {
+                case SRC_FILL: argb_list_batch<SRC_FILL>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+                case SRC_RGB565: argb_list_batch<SRC_RGB565>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+                case SRC_ARGB8888: argb_list_batch<SRC_ARGB8888>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+                case SRC_RGBA8888: argb_list_batch<SRC_RGBA8888>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+                default: argb_list_batch<SRC_ARGB8565>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+            }
+        }
+        wave_lds_fence();
+    }
+
+    for(int i = lane; i < n_chunks; i += 64) {
+        const int row = i / cpr, c = i - row * cpr;
+        *reinterpret_cast<uint4 *>(dst + ((size_t)(ty * LT + row) * W + tx * LT) * 3 + c * 16) = tile4[row * 12 + c];
     }
 }
 
