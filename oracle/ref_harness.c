@@ -561,6 +561,37 @@ REF_API int ref_scene_build(int id)
         lv_obj_set_pos(img2, W / 2 + 40, H / 2 - 40);
         lv_obj_set_style_img_opa(img2, LV_OPA_60, 0);
     }
+    if(id == 3) {
+        /* layers: a half-transparent container with children (simple layer, lv_refr.c layer_type SIMPLE), a rotated and
+         * zoomed object (transform layer with alpha) and a non-normal blend mode on a widget */
+        lv_obj_t * box = lv_obj_create(scr);
+        lv_obj_set_size(box, W / 2, H / 2);
+        lv_obj_set_pos(box, 8, 8);
+        lv_obj_set_style_bg_color(box, lv_color_hex(0x3060C0), 0);
+        lv_obj_set_style_radius(box, 10, 0);
+        lv_obj_set_style_opa(box, LV_OPA_50, 0);
+        lv_obj_t * inner = lv_label_create(box);
+        lv_label_set_text(inner, "layered 50%");
+        lv_obj_t * ib = lv_btn_create(box);
+        lv_obj_set_pos(ib, 10, 30);
+        lv_obj_t * ibl = lv_label_create(ib);
+        lv_label_set_text(ibl, "OK");
+
+        lv_obj_t * rot = lv_obj_create(scr);
+        lv_obj_set_size(rot, 90, 50);
+        lv_obj_set_pos(rot, W / 2, H / 3);
+        lv_obj_set_style_bg_color(rot, lv_color_hex(0xE0A020), 0);
+        lv_obj_set_style_transform_angle(rot, 300, 0);
+        lv_obj_set_style_transform_zoom(rot, 300, 0);
+        lv_obj_t * rl = lv_label_create(rot);
+        lv_label_set_text(rl, "rot");
+
+        lv_obj_t * add = lv_obj_create(scr);
+        lv_obj_set_size(add, W / 3, H / 4);
+        lv_obj_set_pos(add, W / 4, H / 2);
+        lv_obj_set_style_bg_color(add, lv_color_hex(0x404040), 0);
+        lv_obj_set_style_blend_mode(add, LV_BLEND_MODE_ADDITIVE, 0);
+    }
     lv_obj_invalidate(scr);
     return 0;
 }

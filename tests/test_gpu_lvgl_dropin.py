@@ -62,14 +62,16 @@ def _render_sw(R, w, h, scene, flags=0):
     return _fb(R, w, h)
 
 
-@pytest.mark.parametrize("scene", [0, 1, 2])
+@pytest.mark.parametrize("scene", [0, 1, 2, 3])
 @pytest.mark.parametrize("res,flags", [((320, 480), 0), ((480, 320), 0), ((320, 480), 1), ((320, 240), 2), ((200, 96), 3)])
 def test_widget_scene_through_gpu_blend(world, scene, res, flags, request):
-    """flags bit 0: anti-aliasing off (mask thresholding); bit 1: transparent screen (ARGB8565 draw buffer)."""
+    """flags bit 0: anti-aliasing off (mask thresholding); bit 1: transparent screen (ARGB8565 draw buffer).
+    Scene 3 draws through layers (a half-transparent container, a rotated + zoomed object with an alpha layer) and
+    an additive blend mode: the draw context is pointed at layer buffers and back."""
     swap, R, L = world
     w, h = res
     sw = _render_sw(R, w, h, scene, flags)
-    assert len(np.unique(sw)) > 20, "the scene should not be trivial"
+    assert len(np.unique(sw)) > 10, "the scene should not be trivial"
     L.lvgpu_lvgl_reset_stats()
     assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit),
                                L.lvgpu_draw_ctx_size(), None, None, 1, flags) == 0
@@ -81,7 +83,10 @@ def test_widget_scene_through_gpu_blend(world, scene, res, flags, request):
     assert st.blend_gpu > 0 and st.blend_delegated == 0 and st.errors == 0
     assert np.array_equal(got, sw), "%d pixels differ" % int((got != sw).sum())
     if request.node.callspec.params["world"][1]:  # deferred: hundreds of blend calls, a handful of submissions
-        assert 1 <= st.blend_lists <= 4 and st.blend_gpu > 100 * st.blend_lists
+        if scene == 3:  # every layer is a buffer of its own and is submitted before it is read
+            assert 1 <= st.blend_lists <= 40 and st.blend_gpu > 5 * st.blend_lists
+        else:
+            assert 1 <= st.blend_lists <= 4 and st.blend_gpu > 100 * st.blend_lists
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
