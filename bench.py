@@ -80,7 +80,27 @@ def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
     for _ in range(reps):
         O.argb_blend_flush_batch(dst, src, out if want_out else None, W, H, n, args.rotation, args.swap, threads)
     dt = time.perf_counter() - t0
+    ref_lvgl = None
+    try:  # the reference's own blend (LVGL compiled from its sources into oracle/_ref), one thread, blend part only
+        L = O.ref(args.swap)
+        if L is not None:
+            L.ref_init(W, H)
+            nf = 512
+            d3 = O.synth(O.SYNTH_U16, SEED_DST, 0, nf * px).reshape(nf, H, W).copy()
+            s3 = O.synth(O.SYNTH_MASK_UNI, SEED_SRC, 0, nf * px * 3).reshape(nf, H, W, 3).copy()
+            s3[..., 2] = O.synth(O.SYNTH_MASK_UI if args.mask == "ui" else O.SYNTH_MASK_UNI, SEED_MASK, 0, nf * px).reshape(nf, H, W)
+            a16 = O._p(np.array([0, 0, W - 1, H - 1], np.int16))
+            t0 = time.perf_counter()
+            for f in range(nf):
+                L.ref_img_decoded(O._p(d3[f]), a16, a16, a16, O._p(s3[f]), 5, 255, 0, 0, 0)
+            rdt = time.perf_counter() - t0
+            ref_lvgl = {"value": round(nf * px / rdt / 1e6, 1), "unit": "Mpx/s", "cores": 1, "kind": "reference",
+                        "sample": "lv_draw_sw_img_decoded (TRUE_COLOR_ALPHA image over RGB565, blend only, no flush), "
+                                  "%d frames of %dx%d, %.1f s" % (nf, W, H, rdt)}
+    except Exception as e:  # the reference build is optional on the box
+        ref_lvgl = {"error": str(e)}
     return {
+        "reference_lvgl": ref_lvgl,
         "value": round(n * px * reps / dt / 1e6, 1), "unit": "Mpx/s", "cores": threads, "kind": "port",
         "sample": "%d frames of %dx%d x %d passes, %s, %.1f s wall on %d threads (OpenMP over frames)"
                   % (n, W, H, reps, args.workload, dt, threads),
