@@ -212,3 +212,32 @@ def test_blend_argb8565_destination(gpu, oracle, swap):
                            mask_buf=None if mask is None else to_dev(mask), opa=opa, blend_mode=mode)
         gpu.lv_draw_sw_blend(ctx, dsc)
         assert np.array_equal(to_np(d, np.uint8), exp), (t, opa, mode, src is not None, mask is not None)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_blend_argb8565_destination_full_frames(gpu, oracle, swap):
+    """The same semantics over whole, aligned frames: the vector kernel (8 pixels = 24 bytes per lane)."""
+    rng = np.random.default_rng(77 + swap)
+    N = 3
+    for (W, H) in [(64, 24), (480, 320), (40, 5)]:
+        area = (0, 0, W - 1, H - 1)
+        for t in range(40 if W < 480 else 8):
+            dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+            dst[..., 2] = rand_mask(rng, (N, H, W))
+            src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16) if rng.random() < 0.5 else None
+            mask = rand_mask(rng, (N, H, W)) if rng.random() < 0.6 else None
+            opa = int(rng.choice(OPAS))
+            mode = int(rng.choice([0, 0, 1, 2, 3, 4]))
+            color = int(rng.integers(0, 65536))
+            exp = dst.copy()
+            for f in range(N):
+                oracle.blend(exp[f], area, area, area, src=None if src is None else src[f], color=color,
+                             mask=None if mask is None else mask[f], opa=opa, blend_mode=mode, swap=swap, screen_transp=1)
+            d = to_dev(dst)
+            ctx = gpu.DrawCtx(d, area, area, color_16_swap=swap, screen_transp=1)
+            dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                               mask_buf=None if mask is None else to_dev(mask), opa=opa, blend_mode=mode)
+            gpu.lv_draw_sw_blend(ctx, dsc)
+            assert np.array_equal(to_np(d, np.uint8), exp), (W, t, opa, mode, src is not None, mask is not None)
+            if opa > 2:
+                assert gpu.last_kernel() == "k_blend_argb_linear"

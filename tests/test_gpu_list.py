@@ -236,4 +236,7 @@ def test_list_argb8565_destination(gpu, oracle, swap, W, H, N):
         gpu.blend_list(ctx, dscs, clips)
         got = to_np(d, np.uint8)
         assert np.array_equal(got, exp), "scene %d: %d bytes differ" % (scene, int((got != exp).sum()))
-        assert gpu.last_kernel() == ("k_blend_list" if W % 16 == 0 else "k_blend_argb_dst")
+        if W % 16 == 0:
+            assert gpu.last_kernel() == "k_blend_list"
+        else:
+            assert gpu.last_kernel() in ("k_blend_argb_dst", "k_blend_argb_linear")

@@ -241,6 +241,19 @@ struct LaunchArgbDst {
     }
 };
 template <int SRC>
+struct LaunchArgbLinear {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const uint32_t gpf = (uint32_t)(((size_t)a.w * a.h) / 8);
+        const uint32_t cpf = (gpf + 256 * ARGB_UNROLL - 1) / (256 * ARGB_UNROLL);
+        const uint64_t blocks = (uint64_t)cpf * a.n_frames;
+        if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), 0, st, a, gpf, cpf);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+template <int SRC>
 struct LaunchStrip {
     static int run(const BlendArgs & a, hipStream_t st)
     {
@@ -295,9 +308,32 @@ bool tile_ok(const BlendArgs & a, int fmt)
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
 
+// The same question for a 3-byte destination: groups of 8 pixels are 24 bytes, accessed as three 8-byte words.
+bool argb_linear_ok(const BlendArgs & a, int fmt)
+{
+    if(((size_t)a.w * a.h) % 8) return false;
+    if(a.h > 1 && a.dst_stride != a.w) return false;
+    if(!aligned(a.dst, 8) || ((a.dst_fs * 3) % 8)) return false;
+    if(fmt != SRC_FILL) {
+        if(a.h > 1 && a.src_stride != a.w) return false;
+        const size_t bpp = src_bytes_per_px(fmt);
+        const size_t al = fmt == SRC_ARGB8565 ? 8 : 16;
+        if(!aligned(a.src, al) || ((a.src_fs * bpp) % al)) return false;
+    }
+    if(a.mask) {
+        if(a.h > 1 && a.mask_stride != a.w) return false;
+        if(!aligned(a.mask, 8) || (a.mask_fs % 8)) return false;
+    }
+    return true;
+}
+
 int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
 {
     if(argb_dst) {
+        if(argb_linear_ok(a, fmt)) {
+            g_last_kernel = "k_blend_argb_linear";
+            return dispatch_src<LaunchArgbLinear>(fmt, a, st);
+        }
         g_last_kernel = "k_blend_argb_dst";
         return dispatch_src<LaunchArgbDst>(fmt, a, st);
     }

@@ -730,6 +730,82 @@ __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
     }
 }
 
+// Eight ARGB8565 destination pixels held as six dwords (24 bytes): pixel j occupies bytes 3j..3j+2.
+template <int SRC, class A>
+__device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, const uint32_t * sw, uint2 mk, uint32_t color)
+{
+    constexpr bool fill = SRC == SRC_FILL;
+#pragma unroll
+    for(int j = 0; j < 8; j++) {
+        const int byte = 3 * j, w0 = byte >> 2, sh = (byte & 3) * 8;
+        const uint64_t two = (uint64_t)dw[w0] | ((uint64_t)dw[w0 + 1 < 6 ? w0 + 1 : 5] << 32);
+        const uint32_t v = (uint32_t)(two >> sh);
+        uint32_t bg = v & 0xFFFFu;
+        if(a.swap) bg = px_swap16(bg);
+        const uint32_t bg_opa = (v >> 16) & 0xFFu;
+        uint32_t fg = color;
+        uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
+        src_px<SRC>(sw, j, a.swap, fg, m);
+        const ArgbOut r = argb_dst_px(a, fill, fg, m, bg, bg_opa);
+        uint32_t c = a.swap ? px_swap16(r.color) : r.color;
+        uint32_t nv = (r.wc ? c : (v & 0xFFFFu)) | ((r.wo ? r.opa : bg_opa) << 16);
+        // put the 24 bits back (they may straddle two dwords)
+        const uint64_t keep = ~((uint64_t)0xFFFFFFu << sh);
+        const uint64_t upd = (two & keep) | ((uint64_t)(nv & 0xFFFFFFu) << sh);
+        dw[w0] = (uint32_t)upd;
+        if(sh > 8) dw[w0 + 1 < 6 ? w0 + 1 : 5] = (uint32_t)(upd >> 32);
+    }
+}
+
+// ARGB8565 destination over areas that are contiguous in memory: 8 pixels (24 bytes of destination) per lane and
+// access, ARGB_UNROLL groups per lane in flight.  gpf = groups per frame.
+constexpr int ARGB_UNROLL = 2;
+template <int SRC>
+__global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t gpf, uint32_t cpf)
+{
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t f = blk / cpf;
+    const uint32_t c = blk - f * cpf;
+    uint8_t * dst = reinterpret_cast<uint8_t *>(a.dst) + (long long)f * a.dst_fs * 3;
+    const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+    const long long src_px0 = (long long)f * a.src_fs;
+    const uint32_t g0 = c * (256 * ARGB_UNROLL) + threadIdx.x;
+    uint32_t dw[ARGB_UNROLL][6];
+    uint2 mk[ARGB_UNROLL];
+    uint32_t sw[ARGB_UNROLL][SrcWords<SRC>::N];
+    // without a per-pixel alpha and at full opacity colour and alpha are stored whatever the pixel held (:465-477, :768-790)
+    const bool blended = SRC != SRC_FILL && a.raw_mode >= 1 && a.raw_mode <= 3;
+    const bool need_dst = a.has_mask || a.raw_opa < 253 || blended;
+#pragma unroll
+    for(int u = 0; u < ARGB_UNROLL; u++) {
+        const uint32_t g = g0 + u * 256;
+        mk[u] = make_uint2(0, 0);
+        if(g < gpf) {
+            uint2 v0 = make_uint2(0, 0), v1 = v0, v2 = v0;
+            if(need_dst) {
+                const uint2 * p = reinterpret_cast<const uint2 *>(dst + (size_t)g * 24);
+                v0 = p[0];
+                v1 = p[1];
+                v2 = p[2];
+            }
+            dw[u][0] = v0.x; dw[u][1] = v0.y; dw[u][2] = v1.x; dw[u][3] = v1.y; dw[u][4] = v2.x; dw[u][5] = v2.y;
+            if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)g * 8, sw[u]);
+            if(mask) mk[u] = *reinterpret_cast<const uint2 *>(mask + (size_t)g * 8);
+        }
+    }
+#pragma unroll
+    for(int u = 0; u < ARGB_UNROLL; u++) {
+        const uint32_t g = g0 + u * 256;
+        if(g < gpf) {
+            argb_group<SRC>(a, dw[u], sw[u], mk[u], a.color);
+            uint2 * p = reinterpret_cast<uint2 *>(dst + (size_t)g * 24);
+            p[0] = make_uint2(dw[u][0], dw[u][1]);
+            p[1] = make_uint2(dw[u][2], dw[u][3]);
+            p[2] = make_uint2(dw[u][4], dw[u][5]);
+        }
+    }
+}
+
 // Scan index of the first non-black destination pixel of the area, per frame (min-reduction, atomicMin).
 __global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, long long dst_fs, int dst_stride, int w, int h,
                                                         int n_frames, uint32_t * first_nb)

@@ -467,23 +467,66 @@ __device__ __forceinline__ void argb_list_px(const ListItem & it, int swap, uint
     }
 }
 
+// One whole 8-pixel group (24 bytes of the tile) of one item: vector accesses.
+template <int SRC>
+__device__ __forceinline__ void argb_list_group(const ListItem & it, int swap, uint8_t * tile, uint32_t f, int row, int g, int ax,
+                                                int ay)
+{
+    uint2 * p = reinterpret_cast<uint2 *>(tile + row * (LT * 3) + g * 24);
+    const uint2 v0 = p[0], v1 = p[1], v2 = p[2];
+    uint32_t dw[6] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
+    uint32_t sw[SrcWords<SRC>::N];
+    uint2 mk = make_uint2(0, 0);
+    if(SRC != SRC_FILL) load_src_unaligned<SRC>(it.src, (long long)f * it.src_fs + (long long)ay * it.src_stride + ax, sw);
+    if(it.mask) {
+        u32x2_a1 m = *reinterpret_cast<const u32x2_a1 *>(it.mask + (long long)f * it.mask_fs + (long long)ay * it.mask_stride + ax);
+        mk = make_uint2(m.x, m.y);
+    }
+    ArgbLaneView v;
+    v.raw_opa = (int)it.opa;
+    v.raw_mode = it.raw_mode;
+    v.has_mask = it.has_mask;
+    v.swap = swap;
+    argb_group<SRC>(v, dw, sw, mk, it.color);
+    p[0] = make_uint2(dw[0], dw[1]);
+    p[1] = make_uint2(dw[2], dw[3]);
+    p[2] = make_uint2(dw[4], dw[5]);
+}
+
 template <int SRC>
 __device__ __forceinline__ void argb_list_item(const ListItem & it, int swap, uint8_t * tile, uint32_t f, const ListRegion & r, int lane)
 {
-    const uint32_t rw = (uint32_t)(r.x2 - r.x1 + 1), n = rw * (uint32_t)(r.y2 - r.y1 + 1);
+    const int g_lo = (r.x1 + 7) >> 3, g_hi = (r.x2 + 1) >> 3;
+    const uint32_t rh = (uint32_t)(r.y2 - r.y1 + 1);
+    int a_end = r.x2 + 1, b_start = r.x2 + 1;  // columns [x1, a_end) and [b_start, x2] go pixel by pixel
+    if(g_hi > g_lo) {
+        const uint32_t ng = (uint32_t)(g_hi - g_lo), n = ng * rh;
+        const float inv = 1.0f / (float)ng;
+        for(uint32_t idx = (uint32_t)lane; idx < n; idx += 64) {
+            const uint32_t ly = small_div(idx, inv), lg = idx - ly * ng;
+            const int row = r.y1 + (int)ly, g = g_lo + (int)lg;
+            argb_list_group<SRC>(it, swap, tile, f, row, g, g * 8 + r.ox, row + r.oy);
+        }
+        a_end = g_lo * 8;
+        b_start = g_hi * 8;
+    }
+    const uint32_t wa = (uint32_t)(a_end - r.x1), wb = (uint32_t)(r.x2 + 1 - b_start);
+    const uint32_t rw = wa + wb, n = rw * rh;
+    if(n == 0) return;
     const float inv = 1.0f / (float)rw;
     for(uint32_t idx = (uint32_t)lane; idx < n; idx += 64) {
         const uint32_t ly = small_div(idx, inv), lx = idx - ly * rw;
-        const int col = r.x1 + (int)lx, row = r.y1 + (int)ly;
+        const int col = lx < wa ? r.x1 + (int)lx : b_start + (int)(lx - wa), row = r.y1 + (int)ly;
         argb_list_px<SRC>(it, swap, tile, f, row, col, col + r.ox, row + r.oy);
     }
 }
 
 template <int SRC>
 __device__ __forceinline__ void argb_list_batch(const ListArgs & a, uint8_t * tile, uint32_t f, int tx, int ty, uint32_t first,
-                                                uint32_t n, int lane)
+                                                uint32_t n_full, uint32_t n_part, int lane)
 {
     const uint2 * ch = a.chunks + first;
+    const uint32_t n = n_full + n_part;
     for(uint32_t base = 0; base < n; base += 64) {
         const uint32_t idx = base + (uint32_t)lane;
         if(idx >= n) continue;
@@ -492,9 +535,12 @@ __device__ __forceinline__ void argb_list_batch(const ListArgs & a, uint8_t * ti
         const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
         const uint32_t pxmask = (c.y >> 9) & 0xFFu;
         const int ax = tx * LT + g * 8 - it.x1, ay = ty * LT + row - it.y1;
+        if(idx < n_full) argb_list_group<SRC>(it, a.swap, tile, f, row, g, ax, ay);
+        else {
 #pragma unroll
-        for(int j = 0; j < 8; j++)
-            if((pxmask >> j) & 1u) argb_list_px<SRC>(it, a.swap, tile, f, row, g * 8 + j, ax + j, ay);
+            for(int j = 0; j < 8; j++)
+                if((pxmask >> j) & 1u) argb_list_px<SRC>(it, a.swap, tile, f, row, g * 8 + j, ax + j, ay);
+        }
     }
 }
 
@@ -530,7 +576,7 @@ __global__ __launch_bounds__(256) void k_blend_list_argb(ListArgs a)
     uint4 st_next = k0 < k1 ? a.steps[k0] : make_uint4(0, 0, 0, 0);
     for(uint32_t k = k0; k < k1; k++) {
         const uint32_t s_x = __builtin_amdgcn_readfirstlane(st_next.x), s_y = __builtin_amdgcn_readfirstlane(st_next.y);
-        const uint32_t s_n = __builtin_amdgcn_readfirstlane(st_next.z + st_next.w);
+        const uint32_t s_z = __builtin_amdgcn_readfirstlane(st_next.z), s_w = __builtin_amdgcn_readfirstlane(st_next.w);
         if(k + 1 < k1) st_next = a.steps[k + 1];
         if(s_x & LIST_STEP_ITEM) {
             const ListItem & it = a.items[s_x & ~LIST_STEP_ITEM];
@@ -552,11 +598,11 @@ __global__ __launch_bounds__(256) void k_blend_list_argb(ListArgs a)
         }
         else {
             switch(s_x & 7u) {
-                case SRC_FILL: argb_list_batch<SRC_FILL>(a, tile, f, tx, ty, s_y, s_n, lane); break;
-                case SRC_RGB565: argb_list_batch<SRC_RGB565>(a, tile, f, tx, ty, s_y, s_n, lane); break;
-                case SRC_ARGB8888: argb_list_batch<SRC_ARGB8888>(a, tile, f, tx, ty, s_y, s_n, lane); break;
-                case SRC_RGBA8888: argb_list_batch<SRC_RGBA8888>(a, tile, f, tx, ty, s_y, s_n, lane); break;
-                default: argb_list_batch<SRC_ARGB8565>(a, tile, f, tx, ty, s_y, s_n, lane); break;
+                case SRC_FILL: argb_list_batch<SRC_FILL>(a, tile, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGB565: argb_list_batch<SRC_RGB565>(a, tile, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_ARGB8888: argb_list_batch<SRC_ARGB8888>(a, tile, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGBA8888: argb_list_batch<SRC_RGBA8888>(a, tile, f, tx, ty, s_y, s_z, s_w, lane); break;
+                default: argb_list_batch<SRC_ARGB8565>(a, tile, f, tx, ty, s_y, s_z, s_w, lane); break;
             }
         }
         wave_lds_fence();
