@@ -689,7 +689,18 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     a.rot = rot;
     a.swap_out = swap_out;
     if(lb.argb) hipLaunchKernelGGL(k_blend_list_argb, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_blend_list, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else {
+        // two waves per tile pay off when the batches are large enough to keep 128 lanes busy (LVGL's row-by-row
+        // producers: 150+ chunks per batch); lists of many small unrelated items are better off with one
+        const lvgpu_list_plan_t & ps = plan.stats;
+        const bool wide = ps.batch_steps > 0 && (ps.chunks_full + ps.chunks_partial) >= 64 * ps.batch_steps;
+        if(wide)
+            hipLaunchKernelGGL(k_blend_list<2>, dim3((uint32_t)((waves + ListCfg<2>::TPB - 1) / ListCfg<2>::TPB)),
+                               dim3(ListCfg<2>::BLOCK), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_blend_list<1>, dim3((uint32_t)((waves + ListCfg<1>::TPB - 1) / ListCfg<1>::TPB)),
+                               dim3(ListCfg<1>::BLOCK), 0, st, a);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(dev, st));
     lb.clear();

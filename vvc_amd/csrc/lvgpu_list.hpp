@@ -52,6 +52,23 @@ struct ListArgs {
 
 constexpr int LT = 64;  // tile edge, pixels
 
+// Wavefronts that share one tile (WPT; NT = 64 * WPT threads).  With two, the tile's LDS (8 KB) is divided among
+// more waves, so more waves fit a CU (the LDS, not the registers, limits occupancy) and a tile's serial chain of
+// steps gets shorter; the price is a block barrier instead of a wave-level fence between steps, and idle lanes when
+// the steps are small.  The launcher picks WPT from the average batch size of the list.
+template <int WPT>
+struct ListCfg {
+    static constexpr int NT = 64 * WPT;                    // threads per tile
+    static constexpr int BLOCK = WPT == 1 ? 256 : NT;      // threads per block
+    static constexpr int TPB = BLOCK / NT;                 // tiles per block
+};
+template <int WPT>
+__device__ __forceinline__ void tile_fence()
+{
+    if(WPT == 1) wave_lds_fence();
+    else __syncthreads();
+}
+
 // A step is either one item applied to its whole region of the tile (x = LIST_STEP_ITEM | item index), or a batch of
 // chunks (x = kind, y = first chunk, z = number of whole chunks, w = number of partial chunks, whole ones first).
 // A chunk is one 16-byte group of one tile row touched by one small item: x = item index, y = row | group << 6 |
@@ -109,7 +126,7 @@ __device__ __forceinline__ uint32_t small_div(uint32_t idx, float inv_d)
 // Columns [x1, a_end) and [b_start, x2] of the region's rows -- what is left and right of the whole 8-pixel groups,
 // or the whole region when it holds no whole group (a_end = x2 + 1) -- one pixel per lane and step.
 constexpr int LP_UNROLL = 4;
-template <int SRC, int OM, bool BLENDED>
+template <int SRC, int OM, bool BLENDED, int LNT>
 __device__ __forceinline__ void list_pixels(const ListItem & it, uint16_t * tile, uint32_t f, const ListRegion & r, int a_end,
                                             int b_start, int lane)
 {
@@ -117,12 +134,12 @@ __device__ __forceinline__ void list_pixels(const ListItem & it, uint16_t * tile
     const uint32_t rw = wa + wb, n = rw * (uint32_t)(r.y2 - r.y1 + 1);
     if(n == 0) return;
     const float inv = 1.0f / (float)rw;
-    for(uint32_t base = (uint32_t)lane; base < n; base += 64 * LP_UNROLL) {
+    for(uint32_t base = (uint32_t)lane; base < n; base += LNT * LP_UNROLL) {
         uint32_t d[LP_UNROLL], fg[LP_UNROLL], m[LP_UNROLL];
         int li[LP_UNROLL];
 #pragma unroll
         for(int u = 0; u < LP_UNROLL; u++) {
-            const uint32_t idx = base + 64u * u;
+            const uint32_t idx = base + (uint32_t)LNT * u;
             if(idx < n) {
                 const uint32_t ly = small_div(idx, inv), lx = idx - ly * rw;
                 const int col = lx < wa ? r.x1 + (int)lx : b_start + (int)(lx - wa), row = r.y1 + (int)ly;
@@ -135,7 +152,7 @@ __device__ __forceinline__ void list_pixels(const ListItem & it, uint16_t * tile
         }
 #pragma unroll
         for(int u = 0; u < LP_UNROLL; u++) {
-            if(base + 64u * u < n) {
+            if(base + (uint32_t)LNT * u < n) {
                 uint32_t dn = it.swap ? px_swap16(d[u]) : d[u];
                 uint32_t res = px_core_s<OM, BLENDED>(it, dn, fg[u], m[u], 0u, 0u);
                 if(it.swap) res = px_swap16(res);
@@ -147,20 +164,20 @@ __device__ __forceinline__ void list_pixels(const ListItem & it, uint16_t * tile
 
 // Group columns g_lo..g_hi-1 (8 pixels each) of the region's rows, one group per lane and step.
 constexpr int LG_UNROLL = 2;
-template <int SRC, int OM, bool BLENDED>
+template <int SRC, int OM, bool BLENDED, int LNT>
 __device__ __forceinline__ void list_groups(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion & r, int g_lo,
                                             int g_hi, int lane)
 {
     const uint32_t ng = (uint32_t)(g_hi - g_lo), n = ng * (uint32_t)(r.y2 - r.y1 + 1);
     const float inv = 1.0f / (float)ng;
-    for(uint32_t base = (uint32_t)lane; base < n; base += 64 * LG_UNROLL) {
+    for(uint32_t base = (uint32_t)lane; base < n; base += LNT * LG_UNROLL) {
         uint4 d[LG_UNROLL];
         uint2 mk[LG_UNROLL];
         uint32_t sw[LG_UNROLL][SrcWords<SRC>::N];
         int li[LG_UNROLL];
 #pragma unroll
         for(int u = 0; u < LG_UNROLL; u++) {
-            const uint32_t idx = base + 64u * u;
+            const uint32_t idx = base + (uint32_t)LNT * u;
             mk[u] = make_uint2(0, 0);
             if(idx < n) {
                 const uint32_t ly = small_div(idx, inv), lg = idx - ly * ng;
@@ -179,28 +196,28 @@ __device__ __forceinline__ void list_groups(const ListItem & it, uint4 * tile4, 
         }
 #pragma unroll
         for(int u = 0; u < LG_UNROLL; u++) {
-            if(base + 64u * u < n) tile4[li[u]] = blend_group_s<SRC, OM, BLENDED>(it, d[u], sw[u], mk[u], 0u, 0u);
+            if(base + (uint32_t)LNT * u < n) tile4[li[u]] = blend_group_s<SRC, OM, BLENDED>(it, d[u], sw[u], mk[u], 0u, 0u);
         }
     }
 }
 
 // One item on one tile: whole 8-pixel groups of the tile that lie inside the region go as vectors, the columns left
 // and right of them (and regions narrower than a group) pixel by pixel.
-template <int SRC, int OM, bool BLENDED>
+template <int SRC, int OM, bool BLENDED, int LNT>
 __device__ __forceinline__ void list_item(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion r, int lane)
 {
     const int g_lo = (r.x1 + 7) >> 3, g_hi = (r.x2 + 1) >> 3;
     uint16_t * tile = reinterpret_cast<uint16_t *>(tile4);
     if(g_hi > g_lo) {
-        list_groups<SRC, OM, BLENDED>(it, tile4, f, r, g_lo, g_hi, lane);
-        list_pixels<SRC, OM, BLENDED>(it, tile, f, r, g_lo * 8, g_hi * 8, lane);
+        list_groups<SRC, OM, BLENDED, LNT>(it, tile4, f, r, g_lo, g_hi, lane);
+        list_pixels<SRC, OM, BLENDED, LNT>(it, tile, f, r, g_lo * 8, g_hi * 8, lane);
     }
-    else list_pixels<SRC, OM, BLENDED>(it, tile, f, r, r.x2 + 1, r.x2 + 1, lane);
+    else list_pixels<SRC, OM, BLENDED, LNT>(it, tile, f, r, r.x2 + 1, r.x2 + 1, lane);
 }
 
 // Pick the specialisation for the item's (uniform) opacity mode and blend function.  The combinations the host
 // produces are listed; anything else takes the run-time path.
-template <int SRC>
+template <int SRC, int LNT>
 __device__ __forceinline__ void list_dispatch(const ListItem & it, uint4 * tile4, uint32_t f, const ListRegion & r, int lane)
 {
     constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
@@ -208,23 +225,23 @@ __device__ __forceinline__ void list_dispatch(const ListItem & it, uint4 * tile4
     if(normal) {
         switch(it.opa_mode) {
             case OM_CONST:
-                if(!own_alpha && it.opa == 255u) return list_item<SRC, OM_OPAQUE, false>(it, tile4, f, r, lane);
-                if(!own_alpha) return list_item<SRC, OM_CONST, false>(it, tile4, f, r, lane);
+                if(!own_alpha && it.opa == 255u) return list_item<SRC, OM_OPAQUE, false, LNT>(it, tile4, f, r, lane);
+                if(!own_alpha) return list_item<SRC, OM_CONST, false, LNT>(it, tile4, f, r, lane);
                 break;
-            case OM_MASK: return list_item<SRC, OM_MASK, false>(it, tile4, f, r, lane);
+            case OM_MASK: return list_item<SRC, OM_MASK, false, LNT>(it, tile4, f, r, lane);
             case OM_FILL_MASK_OPA:
-                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_MASK_OPA, false>(it, tile4, f, r, lane);
+                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_MASK_OPA, false, LNT>(it, tile4, f, r, lane);
                 break;
             case OM_MAP_MASK_OPA:
-                if(SRC != SRC_FILL) return list_item<SRC, OM_MAP_MASK_OPA, false>(it, tile4, f, r, lane);
+                if(SRC != SRC_FILL) return list_item<SRC, OM_MAP_MASK_OPA, false, LNT>(it, tile4, f, r, lane);
                 break;
             case OM_FILL_PREMULT:
-                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_PREMULT, false>(it, tile4, f, r, lane);
+                if(SRC == SRC_FILL) return list_item<SRC, OM_FILL_PREMULT, false, LNT>(it, tile4, f, r, lane);
                 break;
             default: break;
         }
     }
-    list_item<SRC, OM_RUNTIME, true>(it, tile4, f, r, lane);
+    list_item<SRC, OM_RUNTIME, true, LNT>(it, tile4, f, r, lane);
 }
 
 // What blend_group_s / px_core_s read, per lane (the lanes of a batch may work for different items).
@@ -234,17 +251,17 @@ struct LaneView {
     PremultFill pf;
 };
 
-template <int SRC, int OM, bool BLENDED>
+template <int SRC, int OM, bool BLENDED, int LNT>
 __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, uint32_t f, int tx, int ty, uint32_t first,
                                            uint32_t n_full, uint32_t n_part, int lane)
 {
     const uint2 * ch = a.chunks + first;
     const uint32_t n = n_full + n_part;
     uint2 c_next = lane < (int)n ? ch[lane] : make_uint2(0, 0);
-    for(uint32_t base = 0; base < n; base += 64) {
+    for(uint32_t base = 0; base < n; base += LNT) {
         const uint32_t idx = base + (uint32_t)lane;
         const uint2 c = c_next;
-        if(idx + 64 < n) c_next = ch[idx + 64];  // requested now, used in the next pass
+        if(idx + LNT < n) c_next = ch[idx + LNT];  // requested now, used in the next pass
         if(idx >= n) continue;
         const ListItem & it = a.items[c.x];
         const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
@@ -291,7 +308,7 @@ __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, ui
     }
 }
 
-template <int SRC>
+template <int SRC, int LNT>
 __device__ __forceinline__ void batch_dispatch(const ListArgs & a, uint32_t kind, uint4 * tile4, uint32_t f, int tx, int ty,
                                                uint32_t first, uint32_t n_full, uint32_t n_part, int lane)
 {
@@ -300,34 +317,36 @@ __device__ __forceinline__ void batch_dispatch(const ListArgs & a, uint32_t kind
     if(!(kind & 64u)) {
         switch(om) {
             case OM_OPAQUE:
-                if(!own_alpha) return list_batch<SRC, OM_OPAQUE, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                if(!own_alpha) return list_batch<SRC, OM_OPAQUE, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
                 break;
             case OM_CONST:
-                if(!own_alpha) return list_batch<SRC, OM_CONST, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                if(!own_alpha) return list_batch<SRC, OM_CONST, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
                 break;
-            case OM_MASK: return list_batch<SRC, OM_MASK, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+            case OM_MASK: return list_batch<SRC, OM_MASK, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
             case OM_FILL_MASK_OPA:
-                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_MASK_OPA, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_MASK_OPA, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
                 break;
             case OM_MAP_MASK_OPA:
-                if(SRC != SRC_FILL) return list_batch<SRC, OM_MAP_MASK_OPA, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                if(SRC != SRC_FILL) return list_batch<SRC, OM_MAP_MASK_OPA, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
                 break;
             case OM_FILL_PREMULT:
-                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_PREMULT, false>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+                if(SRC == SRC_FILL) return list_batch<SRC, OM_FILL_PREMULT, false, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
                 break;
             default: break;
         }
     }
-    list_batch<SRC, OM_RUNTIME, true>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
+    list_batch<SRC, OM_RUNTIME, true, LNT>(a, tile4, f, tx, ty, first, n_full, n_part, lane);
 }
 
-__global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
+template <int WPT>
+__global__ __launch_bounds__(ListCfg<WPT>::BLOCK) void k_blend_list(ListArgs a)
 {
-    __shared__ uint4 lds4[4][LT * LT / 8];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
-    if(wt >= a.n_sel * a.n_frames) return;  // waves never wait for each other below
+    constexpr int LNT = ListCfg<WPT>::NT, LIST_TPB = ListCfg<WPT>::TPB;
+    __shared__ uint4 lds4[LIST_TPB][LT * LT / 8];
+    const int lane = threadIdx.x % LNT;  // position among the threads that share the tile
+    const int sub = threadIdx.x / LNT;
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * LIST_TPB + sub);
+    if(wt >= a.n_sel * a.n_frames) return;  // tiles of one block never wait for each other below
     const uint32_t f = wt / a.n_sel;
     const uint32_t sel = a.sel[wt - f * a.n_sel];
     const uint32_t t = sel & 0x7FFFFFFFu;
@@ -335,20 +354,20 @@ __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
     const int ty = (int)(t / a.tiles_x), tx = (int)(t - (uint32_t)ty * a.tiles_x);
     const int W = a.W, H = a.H;
     uint16_t * dst = a.dst + (long long)f * a.dst_fs;
-    uint4 * tile4 = lds4[wave];
+    uint4 * tile4 = lds4[sub];
     uint16_t * tile = reinterpret_cast<uint16_t *>(tile4);
-    const int bx = lane & 7, by = lane >> 3;
-    const int gx = tx * LT + bx * 8;
     const uint32_t k0 = a.bin_start[t], k1 = a.bin_start[t + 1];
+    constexpr int N_ACC = LT * LT / 8 / LNT;  // 16-byte accesses per thread to move the tile
 
-    if(!overwrite && gx < W) {
+    if(!overwrite) {
 #pragma unroll
-        for(int i = 0; i < 8; i++) {
-            const int row = by * 8 + i, y = ty * LT + row;
-            if(y < H) tile4[row * 8 + (bx ^ by)] = *reinterpret_cast<const uint4 *>(dst + (size_t)y * W + gx);
+        for(int i = 0; i < N_ACC; i++) {
+            const int q = lane + LNT * i, row = q >> 3, c = q & 7;
+            const int y = ty * LT + row, gx = tx * LT + c * 8;
+            if(y < H && gx < W) tile4[row * 8 + (c ^ (row >> 3))] = *reinterpret_cast<const uint4 *>(dst + (size_t)y * W + gx);
         }
     }
-    wave_lds_fence();
+    tile_fence<WPT>();
 
     uint4 st_next = k0 < k1 ? a.steps[k0] : make_uint4(0, 0, 0, 0);
     for(uint32_t k = k0; k < k1; k++) {
@@ -362,39 +381,41 @@ __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
             r.x2 = min(it.x2, tx * LT + LT - 1) - tx * LT;
             r.y1 = max(it.y1, ty * LT) - ty * LT;
             r.y2 = min(it.y2, ty * LT + LT - 1) - ty * LT;
-            if(r.x2 < r.x1 || r.y2 < r.y1) continue;
             r.ox = tx * LT - it.x1;  // tile-relative -> area-relative
             r.oy = ty * LT - it.y1;
-            switch(it.fmt) {
-                case SRC_FILL: list_dispatch<SRC_FILL>(it, tile4, f, r, lane); break;
-                case SRC_RGB565: list_dispatch<SRC_RGB565>(it, tile4, f, r, lane); break;
-                case SRC_ARGB8888: list_dispatch<SRC_ARGB8888>(it, tile4, f, r, lane); break;
-                case SRC_RGBA8888: list_dispatch<SRC_RGBA8888>(it, tile4, f, r, lane); break;
-                default: list_dispatch<SRC_ARGB8565>(it, tile4, f, r, lane); break;
+            if(r.x2 >= r.x1 && r.y2 >= r.y1) {
+                switch(it.fmt) {
+                    case SRC_FILL: list_dispatch<SRC_FILL, LNT>(it, tile4, f, r, lane); break;
+                    case SRC_RGB565: list_dispatch<SRC_RGB565, LNT>(it, tile4, f, r, lane); break;
+                    case SRC_ARGB8888: list_dispatch<SRC_ARGB8888, LNT>(it, tile4, f, r, lane); break;
+                    case SRC_RGBA8888: list_dispatch<SRC_RGBA8888, LNT>(it, tile4, f, r, lane); break;
+                    default: list_dispatch<SRC_ARGB8565, LNT>(it, tile4, f, r, lane); break;
+                }
             }
         }
         else {
             switch(s_x & 7u) {
-                case SRC_FILL: batch_dispatch<SRC_FILL>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
-                case SRC_RGB565: batch_dispatch<SRC_RGB565>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
-                case SRC_ARGB8888: batch_dispatch<SRC_ARGB8888>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
-                case SRC_RGBA8888: batch_dispatch<SRC_RGBA8888>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
-                default: batch_dispatch<SRC_ARGB8565>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_FILL: batch_dispatch<SRC_FILL, LNT>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGB565: batch_dispatch<SRC_RGB565, LNT>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_ARGB8888: batch_dispatch<SRC_ARGB8888, LNT>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                case SRC_RGBA8888: batch_dispatch<SRC_RGBA8888, LNT>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
+                default: batch_dispatch<SRC_ARGB8565, LNT>(a, s_x, tile4, f, tx, ty, s_y, s_z, s_w, lane); break;
             }
         }
-        wave_lds_fence();
+        tile_fence<WPT>();
     }
 
-    if(gx < W) {
+    {
         const bool wr_dst = k1 > k0;
         uint16_t * out = a.out ? a.out + (long long)f * a.out_fs : nullptr;
         const bool linear_out = out && (a.rot == 0 || a.rot == 2);
         const size_t area = (size_t)W * H;
 #pragma unroll
-        for(int i = 0; i < 8; i++) {
-            const int row = by * 8 + i, y = ty * LT + row;
-            if(y < H) {
-                uint4 v = tile4[row * 8 + (bx ^ by)];
+        for(int i = 0; i < N_ACC; i++) {
+            const int q = lane + LNT * i, row = q >> 3, c = q & 7;
+            const int y = ty * LT + row, gx = tx * LT + c * 8;
+            if(y < H && gx < W) {
+                uint4 v = tile4[row * 8 + (c ^ (row >> 3))];
                 const size_t p = (size_t)y * W + gx;
                 if(wr_dst) *reinterpret_cast<uint4 *>(dst + p) = v;
                 if(linear_out) {
@@ -407,11 +428,10 @@ __global__ __launch_bounds__(256) void k_blend_list(ListArgs a)
     }
     if(a.out && (a.rot == 1 || a.rot == 3)) {  // H % 8 == 0 (checked by the launcher)
         uint16_t * out = a.out + (long long)f * a.out_fs;
-        const int rr = lane >> 3, c = lane & 7;
-        const int yb = ty * LT + c * 8;
 #pragma unroll
-        for(int k = 0; k < 8; k++) {
-            const int xl = k * 8 + rr;
+        for(int k = 0; k < N_ACC; k++) {
+            const int q = lane + LNT * k, xl = q >> 3, c = q & 7;
+            const int yb = ty * LT + c * 8;
             const int X = tx * LT + xl;
             if(X < W && yb < H) {
                 uint32_t px[8];
