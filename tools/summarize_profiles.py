@@ -47,3 +47,31 @@ for w, kname in KERNEL.items():
         print(w, "traffic/algorithmic = %.3f" % summ["traffic_over_algorithmic"])
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+
+# display-list kernel (tools/collect_list_profile.sh): kernel stats + HBM traffic + issue counters in one summary
+lsrc = os.path.join(src, "list")
+if os.path.isdir(lsrc):
+    import collections
+    st = glob.glob(os.path.join(lsrc, "kt", "*", "*_kernel_stats.csv"))
+    if st:
+        rows = list(csv.reader(open(st[0])))
+        with open(os.path.join(dst, "list_scene2_kernel_stats.csv"), "w") as f:
+            csv.writer(f).writerows(rows)
+    out = {"workload": "display list: golden LVGL scene 2 (1649 descriptors, 432119 drawn px per frame) replayed over 4096 "
+                       "frames of 480x320 + fused 90-degree flush", "kernel": "k_blend_list"}
+    for c in ("fetch", "write", "sq"):
+        files = glob.glob(os.path.join(lsrc, c, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if "k_blend_list" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out[k + "_avg_per_launch"] = sum(v) / len(v)
+    if "FETCH_SIZE_avg_per_launch" in out and "WRITE_SIZE_avg_per_launch" in out:
+        out["hbm_read_bytes_per_launch(FETCH_SIZE*1024*2)"] = out["FETCH_SIZE_avg_per_launch"] * 2048
+        out["hbm_write_bytes_per_launch"] = out["WRITE_SIZE_avg_per_launch"] * 1024
+        out["minimum_bytes_per_launch(2 B dst write + 2 B panel write per px)"] = 4 * 480 * 320 * 4096
+    json.dump(out, open(os.path.join(dst, "list_scene2_pmc_summary.json"), "w"), indent=1)
+    print("list: VALU wave-instructions per launch %.0f" % out.get("SQ_INSTS_VALU_avg_per_launch", float("nan")))
