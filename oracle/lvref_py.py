@@ -210,7 +210,8 @@ def ref_available(swap=1):
 def ref(swap=1):
     """The real LVGL build with LV_COLOR_16_SWAP == swap, or None if oracle/_ref was not built."""
     if swap not in _ref:
-        so = os.path.join(_HERE, "_ref", "liblvgl_swap%d.so" % swap)
+        # LVREF_REF_DIR: another build of the same recipe (e.g. other optimisation flags for a baseline measurement)
+        so = os.path.join(os.environ.get("LVREF_REF_DIR", os.path.join(_HERE, "_ref")), "liblvgl_swap%d.so" % swap)
         if not os.path.exists(so):
             _ref[swap] = None
             return None
