@@ -203,17 +203,19 @@ def main():
     def barrier():
         sharding.barrier(dist)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # on the stream the kernels go to
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
-    ev1.record()
+        evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    dt, ev_ms = sharding.max_over_ranks(dist, [dt, ev_ms])
+    ev_ms = evs[0].elapsed_time(evs[-1])
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    ev_median = per_step[len(per_step) // 2] if per_step else 0.0
+    dt, ev_ms, ev_median = sharding.max_over_ranks(dist, [dt, ev_ms, ev_median])
 
     eighth = None
     if rank == 0 and world == 1 and not args.no_eighth:
@@ -257,6 +259,7 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": kernel, "algorithmic_bytes_per_px": bpp, "launch_ms": round(launch_s * 1e3, 4),
+                "launch_ms_median": round(ev_median, 4),
             },
             "pct_hbm_peak": round(100 * achieved / HBM_PEAK_GBS, 2),
         }
