@@ -254,6 +254,27 @@ int lvgpu_color_to32(const uint16_t * dev_in, uint32_t * dev_out, size_t n, int 
  * src_format is LVGPU_SRC_ARGB8888, LVGPU_SRC_RGBA8888 or LVGPU_SRC_ARGB8565. */
 int lvgpu_image_split(const void * dev_src, int src_format, uint16_t * dev_color, uint8_t * dev_alpha, size_t n,
                       int color_16_swap, void * stream);
+/*
+ * What lv_draw_sw_img_decoded puts into its colour and alpha buffers before it blends them, for a whole image:
+ * convert_cb (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:203-298) followed by the recolor pass (:163-174).
+ * src_format LVGPU_SRC_RGB565 is LV_IMG_CF_TRUE_COLOR (alpha 0xFF everywhere, :215-216) or, with
+ * opts->chroma_keyed, LV_IMG_CF_TRUE_COLOR_CHROMA_KEYED (alpha 0 where the pixel equals opts->chroma_key, :230-247);
+ * the formats with their own alpha are split as in lvgpu_image_split.  With opts->recolor_opa > LV_OPA_MIN every
+ * colour becomes lv_color_mix_premult(lv_color_premult(recolor, recolor_opa), colour, 255 - recolor_opa).
+ * The two planes are then drawn with lvgpu_blend_batch (src = colour plane, LVGPU_SRC_RGB565; mask = alpha plane;
+ * mask_res FULL_COVER for a plain LV_IMG_CF_TRUE_COLOR image, :128-131).  Image assets are converted once and the
+ * planes shared by all frames (src_frame_stride = mask_frame_stride = 0).  opts == NULL: no key, no recolor.
+ */
+typedef struct {
+    int32_t chroma_keyed;
+    uint16_t chroma_key;  /* LV_COLOR_CHROMA_KEY as stored (lv_color_t.full) */
+    uint16_t recolor;     /* lv_draw_img_dsc_t.recolor.full                  */
+    uint8_t recolor_opa;  /* lv_draw_img_dsc_t.recolor_opa                   */
+    uint8_t reserved[3];
+} lvgpu_image_opts_t;
+
+int lvgpu_image_convert(const void * dev_src, int src_format, uint16_t * dev_color, uint8_t * dev_alpha, size_t n,
+                        int color_16_swap, const lvgpu_image_opts_t * opts, void * stream);
 /* lv_color_fill (libraries/lvgl/src/misc/lv_color.c:36-77). */
 int lvgpu_color_fill(uint16_t * dev_buf, uint16_t color, size_t n, void * stream);
 /* lv_draw_sw_buffer_copy (libraries/lvgl/src/draw/sw/lv_draw_sw.c:81-104) over n_frames buffers. */

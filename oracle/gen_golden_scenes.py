@@ -48,6 +48,38 @@ def main():
                 hor, ver = (LW, LH) if r == 2 else (LH, LW)
                 arrays["lv_rot%d_%dx%d" % (r, LW, LH)] = O.render_scene(L, hor, ver, 2, 4 | (r << 3))
         L.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+        # images drawn by LVGL with recolor / chroma key (lv_draw_sw_img.c:163-174, :203-298): inputs and LVGL's buffer
+        img = {}
+        rng = np.random.default_rng(2024)
+        key = int(O.lib().lvref_color_hex(0x00FF00, swap))  # LV_COLOR_CHROMA_KEY of the firmware configuration
+        IW, IH, coords = 96, 40, (3, 2, 90, 35)
+        iw, ih = coords[2] - coords[0] + 1, coords[3] - coords[1] + 1
+        c16 = np.array(coords, np.int16)
+        full = np.array([0, 0, IW - 1, IH - 1], np.int16)
+        cases = []
+        for cf in (4, 6, 5):
+            for recolor_opa, opa in ((0, 255), (3, 255), (128, 180), (255, 255)):
+                if cf == 5:
+                    src = rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8)
+                    src[..., 2] = rng.choice(np.array([0, 255, 1, 2, 127, 128, 253, 254], np.uint8), (ih, iw))
+                else:
+                    src = rng.integers(0, 65536, (ih, iw), dtype=np.uint16)
+                    src[rng.random((ih, iw)) < 0.3] = key
+                recolor = int(rng.integers(0, 65536))
+                dst = rng.integers(0, 65536, (IH, IW), dtype=np.uint16)
+                k = len(cases)
+                img["src%d" % k], img["dst%d" % k] = src, dst.copy()
+                L.ref_init(IW, IH)
+                L.ref_img_decoded(O._p(dst), O._p(full), O._p(c16), O._p(c16), O._p(src), cf, opa, recolor, recolor_opa, 0)
+                L.ref_init(480, 480)
+                img["out%d" % k] = dst
+                cases.append([cf, recolor, recolor_opa, opa])
+        img["cases"] = np.array(cases, np.int32)
+        img["coords"] = c16
+        img["chroma_key"] = np.array([key], np.int32)
+        path = os.path.join(GOLD, "lvgl_image_recolor_swap%d.npz" % swap)
+        np.savez_compressed(path, **img)
+        print(path, os.path.getsize(path), "bytes")
         path = os.path.join(GOLD, "lvgl_sw_rotate_swap%d.npz" % swap)
         np.savez_compressed(path, **arrays)
         print(path, os.path.getsize(path), "bytes")

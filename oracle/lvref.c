@@ -469,6 +469,30 @@ void lvref_image_split(const void * src, int format, uint16_t * color, uint8_t *
     }
 }
 
+/* What lv_draw_sw_img_decoded puts into its colour and alpha buffers for n pixels of an image before it blends them:
+ * convert_cb (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:203-298) -- format 1 = LV_IMG_CF_TRUE_COLOR (alpha stays
+ * 0xFF, :215-216), with chroma_keyed != 0 LV_IMG_CF_TRUE_COLOR_CHROMA_KEYED (pixels equal to the key get alpha 0,
+ * :230-247); formats 2/3/4 as lvref_image_split -- followed by the recolor pass (:163-174): every colour becomes
+ * lv_color_mix_premult(premult(recolor, recolor_opa), colour, 255 - recolor_opa) when recolor_opa > LV_OPA_MIN. */
+void lvref_image_convert(const void * src, int format, uint16_t * color, uint8_t * alpha, size_t n, int swap,
+                         int chroma_keyed, uint16_t chroma_key, uint16_t recolor, uint8_t recolor_opa)
+{
+    if(format == 1) {
+        const uint16_t * s = (const uint16_t *)src;
+        for(size_t i = 0; i < n; i++) {
+            color[i] = s[i];
+            alpha[i] = (chroma_keyed && s[i] == chroma_key) ? 0x00 : 0xFF;
+        }
+    }
+    else lvref_image_split(src, format, color, alpha, n, swap);
+    if(recolor_opa > OPA_MIN) {
+        uint16_t pm[3];
+        lvref_color_premult(recolor, recolor_opa, pm, swap);
+        uint8_t inv = (uint8_t)(255 - recolor_opa);
+        for(size_t i = 0; i < n; i++) color[i] = lvref_color_mix_premult(pm, color[i], inv, swap);
+    }
+}
+
 /* libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:98-195 with no transform, no recolor, no extra draw masks. */
 int lvref_img_blend(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, lvref_area_t coords, const void * src,
                     int format, uint8_t opa, int swap, int hor_res)

@@ -66,6 +66,8 @@ int lvref_blend(const lvref_blend_t * b);
 /* format: 2 = ARGB8888 bytes {B,G,R,A}, 3 = RGBA8888 bytes {R,G,B,A}, 4 = ARGB8565 3 B/px {c.lo,c.hi,A}
  * (libraries/lvgl/src/extra/libs/png/lv_png.c:244-253, libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:249-275). */
 void lvref_image_split(const void * src, int format, uint16_t * color, uint8_t * alpha, size_t n, int swap);
+void lvref_image_convert(const void * src, int format, uint16_t * color, uint8_t * alpha, size_t n, int swap,
+                         int chroma_keyed, uint16_t chroma_key, uint16_t recolor, uint8_t recolor_opa);
 
 /* An image with per-pixel alpha drawn over a buffer the way lv_draw_sw_img_decoded's generic branch does it
  * (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:98-195): split into colour + alpha for at most hor_res pixels'

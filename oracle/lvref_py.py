@@ -96,6 +96,8 @@ def lib():
         L.lvref_blend.restype = C.c_int
         L.lvref_blend.argtypes = [C.POINTER(BlendDsc)]
         L.lvref_image_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.lvref_image_convert.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                          C.c_uint16, C.c_uint16, C.c_uint8]
         L.lvref_img_blend.restype = C.c_int
         L.lvref_img_blend.argtypes = [C.c_void_p, Area, Area, Area, C.c_void_p, C.c_int, C.c_uint8, C.c_int, C.c_int]
         L.lvref_flush.restype = C.c_int
@@ -141,6 +143,16 @@ def image_split(src, fmt, swap):
     color = np.empty(n, np.uint16)
     alpha = np.empty(n, np.uint8)
     lib().lvref_image_split(_p(np.ascontiguousarray(src)), fmt, _p(color), _p(alpha), n, swap)
+    return color, alpha
+
+
+def image_convert(src, fmt, swap, chroma_keyed=0, chroma_key=0, recolor=0, recolor_opa=0):
+    """convert_cb + recolor of lv_draw_sw_img_decoded: (colour plane, alpha plane) of an image."""
+    src = np.ascontiguousarray(src)
+    n = src.size // (3 if fmt == SRC_ARGB8565 else 1)
+    color = np.empty(n, np.uint16)
+    alpha = np.empty(n, np.uint8)
+    lib().lvref_image_convert(_p(src), fmt, _p(color), _p(alpha), n, swap, chroma_keyed, chroma_key, recolor, recolor_opa)
     return color, alpha
 
 

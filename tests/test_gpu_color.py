@@ -68,3 +68,44 @@ def test_synth_and_checksum_match_cpu_definition(gpu, oracle):
     ab = gpu.synth(gpu.SYNTH_U16, 5, 0, (1500,))
     assert torch.equal(torch.cat([a, b]), ab)
     assert (gpu.checksum(a, 0) + gpu.checksum(b, 1000)) & 0xFFFFFFFFFFFFFFFF == gpu.checksum(ab, 0)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_image_convert_recolor_chroma_key(gpu, oracle, swap):
+    """lvgpu_image_convert against the oracle's convert_cb + recolor on random images, and end to end against the
+    buffers the real LVGL drew (golden): GPU-converted planes blended on the GPU."""
+    import os
+    import torch
+    rng = np.random.default_rng(5 + swap)
+    key = int(oracle.lib().lvref_color_hex(0x00FF00, swap))
+    for fmt in (1, 2, 3, 4):
+        for recolor_opa in (0, 2, 3, 77, 255):
+            n = 5000
+            if fmt == 1:
+                src = rng.integers(0, 65536, n, dtype=np.uint16)
+                src[rng.random(n) < 0.2] = key
+            elif fmt == 4:
+                src = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+            else:
+                src = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+            recolor = int(rng.integers(0, 65536))
+            for keyed in ((0, 1) if fmt == 1 else (0,)):
+                ec, ea = oracle.image_convert(src, fmt, swap, chroma_keyed=keyed, chroma_key=key, recolor=recolor,
+                                              recolor_opa=recolor_opa)
+                gc, ga = gpu.image_convert(to_dev(src), fmt, swap, chroma_key=key if keyed else None, recolor=recolor,
+                                           recolor_opa=recolor_opa)
+                assert np.array_equal(to_np(gc, np.uint16), ec) and np.array_equal(to_np(ga, np.uint8), ea), (fmt, recolor_opa)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lvgl_image_recolor_swap%d.npz" % swap))
+    coords = tuple(int(v) for v in z["coords"])
+    gkey = int(z["chroma_key"][0])
+    iw, ih = coords[2] - coords[0] + 1, coords[3] - coords[1] + 1
+    for k, (cf, recolor, recolor_opa, opa) in enumerate(z["cases"].tolist()):
+        src, dst, out = z["src%d" % k], z["dst%d" % k], z["out%d" % k]
+        c, a = gpu.image_convert(to_dev(src), 4 if cf == 5 else 1, swap, chroma_key=gkey if cf == 6 else None,
+                                 recolor=recolor, recolor_opa=recolor_opa)
+        d = to_dev(np.repeat(dst[None], 2, axis=0))
+        ctx = gpu.DrawCtx(d, clip_area=coords, color_16_swap=swap)
+        dsc = gpu.BlendDsc(coords, src_buf=c.view(ih, iw), mask_buf=None if cf == 4 else a.view(ih, iw), opa=opa)
+        gpu.lv_draw_sw_blend(ctx, dsc)
+        got = to_np(d, np.uint16)
+        assert np.array_equal(got[0], out) and np.array_equal(got[1], out), (k, cf, recolor_opa, opa)

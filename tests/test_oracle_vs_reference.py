@@ -104,3 +104,46 @@ def test_image_with_alpha_draw(oracle, ref):
         L.ref_init(480, 480)
         oracle.img_blend(d2, (0, 0, W - 1, H - 1), clip, coords, src, oracle.SRC_ARGB8565, opa, swap, W)
         assert np.array_equal(d1, d2)
+
+
+def _lvgl_image_draw(oracle, L, dst, W, H, coords, src, cf, opa, recolor, recolor_opa):
+    L.ref_init(W, H)
+    area = np.array([0, 0, W - 1, H - 1], np.int16)
+    # lv_draw_img hands lv_draw_sw_img_decoded a clip area that lies within the image (lv_draw_img.c:236-262)
+    c16 = np.array(coords, np.int16)
+    L.ref_img_decoded(oracle._p(dst), oracle._p(area), oracle._p(c16), oracle._p(c16), oracle._p(src), cf, opa, recolor,
+                      recolor_opa, 0)
+    L.ref_init(480, 480)
+
+
+def test_image_convert_recolor_chroma_key(oracle, ref):
+    """convert_cb + the recolor pass of lv_draw_sw_img_decoded (lv_draw_sw_img.c:163-174, :203-298): plain, chroma-keyed
+    and alpha images, recolored or not, drawn by the real LVGL; the oracle converts the image (colour + alpha plane)
+    and blends the planes."""
+    swap, L = ref
+    rng = np.random.default_rng(21)
+    key = int(oracle.lib().lvref_color_hex(0x00FF00, swap))  # LV_COLOR_CHROMA_KEY, src/lv_conf.h:42
+    W, H = 96, 40
+    coords = (3, 2, 90, 35)
+    iw, ih = coords[2] - coords[0] + 1, coords[3] - coords[1] + 1
+    area = (0, 0, W - 1, H - 1)
+    for cf, fmt in ((4, 1), (6, 1), (5, 4)):  # LV_IMG_CF_TRUE_COLOR, _CHROMA_KEYED, _ALPHA
+        for recolor_opa in (0, 2, 3, 128, 250, 255):
+            for opa in (255, 180):
+                if fmt == 1:
+                    src = rng.integers(0, 65536, (ih, iw), dtype=np.uint16)
+                    src[rng.random((ih, iw)) < 0.3] = key
+                else:
+                    src = rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8)
+                    src[..., 2] = rand_mask(rng, (ih, iw))
+                recolor = int(rng.integers(0, 65536))
+                dst = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+                d1, d2 = dst.copy(), dst.copy()
+                _lvgl_image_draw(oracle, L, d1, W, H, coords, src, cf, opa, recolor, recolor_opa)
+                color, alpha = oracle.image_convert(src, fmt, swap, chroma_keyed=int(cf == 6), chroma_key=key,
+                                                    recolor=recolor, recolor_opa=recolor_opa)
+                # a plain image without recolor is blended without any mask (:65-70); otherwise the alpha plane is the
+                # mask, with mask_res FULL_COVER (= ignored) for LV_IMG_CF_TRUE_COLOR (:128-131)
+                mask = None if cf == 4 else alpha.reshape(ih, iw)
+                oracle.blend(d2, area, area, coords, src=color.reshape(ih, iw), mask=mask, opa=opa, swap=swap)
+                assert np.array_equal(d1, d2), (cf, recolor_opa, opa)

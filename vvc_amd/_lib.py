@@ -111,6 +111,7 @@ def lib():
         "lvgpu_color_from_rgb888": (C.c_int, [vp, vp, sz, C.c_int, vp]),
         "lvgpu_color_to32": (C.c_int, [vp, vp, sz, C.c_int, vp]),
         "lvgpu_image_split": (C.c_int, [vp, C.c_int, vp, vp, sz, C.c_int, vp]),
+        "lvgpu_image_convert": (C.c_int, [vp, C.c_int, vp, vp, sz, C.c_int, C.POINTER(ImageOpts), vp]),
         "lvgpu_color_fill": (C.c_int, [vp, C.c_uint16, sz, vp]),
         "lvgpu_buffer_copy_batch": (C.c_int, [vp, i64, i32, Area, vp, i64, i32, Area, i32, vp]),
         "lvgpu_synth": (C.c_int, [vp, C.c_int, u64, u64, sz, vp]),
@@ -146,6 +147,12 @@ class ListPlan(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class ImageOpts(C.Structure):
+    """lvgpu_image_opts_t"""
+    _fields_ = [("chroma_keyed", C.c_int32), ("chroma_key", C.c_uint16), ("recolor", C.c_uint16), ("recolor_opa", C.c_uint8),
+                ("reserved", C.c_uint8 * 3)]
 
 
 class FlushChunk(C.Structure):

@@ -1081,6 +1081,30 @@ int lvgpu_image_split(const void * src, int fmt, uint16_t * color, uint8_t * alp
     HIP_TRY(hipGetLastError());
     return LVGPU_OK;
 }
+int lvgpu_image_convert(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap,
+                        const lvgpu_image_opts_t * opts, void * stream)
+{
+    if(n == 0) return LVGPU_OK;
+    if(!src || !color || !alpha) return fail(LVGPU_ERR_ARG, "NULL buffer");
+    if(fmt < LVGPU_SRC_RGB565 || fmt > LVGPU_SRC_ARGB8565) return fail(LVGPU_ERR_ARG, "bad src_format %d", fmt);
+    lvgpu_image_opts_t o;
+    memset(&o, 0, sizeof(o));
+    if(opts) o = *opts;
+    PremultFill rc;
+    memset(&rc, 0, sizeof(rc));
+    const int recolor = o.recolor_opa > 2 ? 1 : 0;  // LV_OPA_MIN, lv_draw_sw_img.c:163
+    if(recolor) {                                   // lv_color_premult, lv_color.h:474-488
+        const uint32_t c = swap ? bswap16(o.recolor) : o.recolor;
+        rc.pm_r = (c >> 11) * o.recolor_opa;
+        rc.pm_g = ((c >> 5) & 0x3Fu) * o.recolor_opa;
+        rc.pm_b = (c & 0x1Fu) * o.recolor_opa;
+        rc.opa_inv = 255u - o.recolor_opa;
+    }
+    hipLaunchKernelGGL(k_image_convert, stream_grid(n), dim3(256), 0, (hipStream_t)stream, src, fmt, color, alpha, n, swap ? 1 : 0,
+                       o.chroma_keyed ? 1 : 0, (uint32_t)o.chroma_key, recolor, rc);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
 int lvgpu_color_fill(uint16_t * buf, uint16_t color, size_t n, void * stream)
 {
     if(n == 0) return LVGPU_OK;

@@ -894,6 +894,38 @@ __global__ void k_image_split(const void * src, int fmt, uint16_t * color, uint8
         alpha[i] = (uint8_t)al;
     }
 }
+// convert_cb + recolor: fmt SRC_RGB565 copies the colour (alpha 255, or 0 where it equals the chroma key); rc.opa_inv
+// == 255 means "no recolor" (lv_color_mix_premult with nothing premultiplied and mix 255 would not be the identity
+// in general, so it is skipped as the reference skips it).
+__global__ void k_image_convert(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap, int keyed,
+                                uint32_t key, int recolor, PremultFill rc)
+{
+    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t c, al;  // c: stored lv_color_t
+        if(fmt == SRC_RGB565) {
+            c = reinterpret_cast<const uint16_t *>(src)[i];
+            al = (keyed && c == key) ? 0u : 255u;
+        }
+        else if(fmt == SRC_ARGB8565) {
+            const uint8_t * p = reinterpret_cast<const uint8_t *>(src) + i * 3;
+            c = p[0] | (p[1] << 8);
+            al = p[2];
+        }
+        else {
+            uint32_t v = reinterpret_cast<const uint32_t *>(src)[i];
+            c = fmt == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+            if(swap) c = px_swap16(c);
+            al = v >> 24;
+        }
+        if(recolor) {
+            uint32_t nat = swap ? px_swap16(c) : c;
+            nat = px_mix_premult(rc, nat);
+            c = swap ? px_swap16(nat) : nat;
+        }
+        color[i] = (uint16_t)c;
+        alpha[i] = (uint8_t)al;
+    }
+}
 __global__ void k_fill16(uint16_t * buf, uint16_t color, size_t n)
 {
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) buf[i] = color;

@@ -232,6 +232,20 @@ def check_count(rc):
     return rc
 
 
+def image_convert(src, src_format, color_16_swap=1, chroma_key=None, recolor=0, recolor_opa=0, stream=None):
+    """Colour and alpha planes of an image as lv_draw_sw_img_decoded prepares them (convert_cb + recolor);
+    chroma_key: the stored LV_COLOR_CHROMA_KEY value for LV_IMG_CF_TRUE_COLOR_CHROMA_KEYED images, else None."""
+    n = src.numel() // 3 if src_format == SRC_ARGB8565 else src.numel()
+    color = torch.empty(n, dtype=torch.int16, device=src.device)
+    alpha = torch.empty(n, dtype=torch.uint8, device=src.device)
+    o = _lib.ImageOpts()
+    o.chroma_keyed, o.chroma_key = (0, 0) if chroma_key is None else (1, int(chroma_key))
+    o.recolor, o.recolor_opa = int(recolor), int(recolor_opa)
+    check(_lib.lib().lvgpu_image_convert(src.data_ptr(), src_format, color.data_ptr(), alpha.data_ptr(), n, color_16_swap,
+                                          C.byref(o), _stream(stream)))
+    return color, alpha
+
+
 class BlendList:
     """A display list marshalled once and replayed many times (the descriptors, their sources and masks and ctx.buf
     must stay alive and in place)."""
