@@ -278,7 +278,21 @@ struct LaunchRows {
         const uint32_t gmax = ((uint32_t)a.w + 7 + 7) / 8;  // groups per row for the worst row alignment
         const uint64_t lanes = (uint64_t)gmax * (uint32_t)a.h;
         dim3 grid((uint32_t)((lanes + 255) / 256), std::min<uint32_t>(a.n_frames, 65535));
-        hipLaunchKernelGGL(k_blend_rows<SRC>, grid, dim3(256), 0, st, a, gmax);
+        // the combinations resolve_blend produces with the normal blend function; everything else decides per pixel
+        constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
+        const bool normal = a.blend_fn == BF_NORMAL;
+        if(normal && a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha && SRC != SRC_COPY)
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), 0, st, a, gmax);
+        else if(normal && a.opa_mode == OM_CONST && !own_alpha && SRC != SRC_COPY)
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), 0, st, a, gmax);
+        else if(normal && a.opa_mode == OM_MASK && SRC != SRC_COPY)
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), 0, st, a, gmax);
+        else if(normal && a.opa_mode == OM_FILL_MASK_OPA && SRC == SRC_FILL)
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), 0, st, a, gmax);
+        else if(normal && a.opa_mode == OM_MAP_MASK_OPA && SRC != SRC_FILL && SRC != SRC_COPY)
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), 0, st, a, gmax);
+        else
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), 0, st, a, gmax);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }

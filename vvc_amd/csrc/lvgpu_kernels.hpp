@@ -564,7 +564,9 @@ __device__ __forceinline__ void blend_one_px(const BlendArgs & a, uint32_t f, ui
     *dp = (uint16_t)r;
 }
 
-template <int SRC>
+// OM: the opacity mode fixed at compile time (the launcher picks it; OM_RUNTIME for the blend modes and anything
+// else) -- this kernel spends its time issuing integer instructions, not waiting for memory.
+template <int SRC, int OM>
 __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
@@ -586,7 +588,8 @@ __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax)
                 u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(a.mask + (long long)f * a.mask_fs + (size_t)y * a.mask_stride + x_lo);
                 mk = make_uint2(v.x, v.y);
             }
-            *reinterpret_cast<uint4 *>(row + x_lo) = blend_group<SRC>(a, d, sw, mk, y * (uint32_t)a.w + (uint32_t)x_lo, fnb);
+            *reinterpret_cast<uint4 *>(row + x_lo) =
+                blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d, sw, mk, y * (uint32_t)a.w + (uint32_t)x_lo, fnb);
         }
         else {
             for(int j = 0; j < 8; j++) {
