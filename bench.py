@@ -203,18 +203,25 @@ def main():
     def barrier():
         sharding.barrier(dist)
 
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # on the stream the kernels go to
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # on the launch stream
     barrier()
     t0 = time.perf_counter()
-    evs[0].record()
-    for i in range(args.steps):
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        evs[i + 1].record()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
-    ev_ms = evs[0].elapsed_time(evs[-1])
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-    ev_median = per_step[len(per_step) // 2] if per_step else 0.0
+    ev_ms = ev0.elapsed_time(ev1)
+    # outside the timed region: a few launches bracketed one by one, for the median launch time
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+    evs[0].record()
+    for i in range(11):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(11))
+    ev_median = per_step[5]
     dt, ev_ms, ev_median = sharding.max_over_ranks(dist, [dt, ev_ms, ev_median])
 
     eighth = None
