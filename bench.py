@@ -108,6 +108,57 @@ def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
     }
 
 
+def cpu_baseline_scene(args, W, H, rec, d_first, o_first):
+    """The scene workload on the host: the oracle replays the recorded descriptors frame by frame (OpenMP over frames)
+    and applies the restated flush rotation; where the real LVGL (oracle/_ref) is present it also renders the same
+    widget scene itself, rasterisers included, on one thread."""
+    import ctypes as C
+    import numpy as np
+    from oracle import lvref_py as O
+    O.build()
+    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+    px = W * H
+    n = 256
+    prepared = O.prepare_list([dict(area=r["area"], src=r["src"], mask=r["mask"], color=r["color"], opa=r["opa"],
+                                    blend_mode=r["blend_mode"]) for r in rec], W, H, args.swap)
+    dst = O.synth(O.SYNTH_U16, SEED_DST, 0, n * px).reshape(n, H, W).copy()
+    out = np.empty(n * px, np.uint16)
+    O.list_flush_batch(dst, prepared, out, n, args.rotation, threads)
+    ok = bool(np.array_equal(dst[:4].reshape(-1), d_first)) and bool(np.array_equal(out[: 4 * px], o_first))
+    t0 = time.perf_counter()
+    O.list_flush_batch(dst, prepared, out, n, args.rotation, threads)
+    once = time.perf_counter() - t0
+    reps = max(1, min(1000, int(1.5 / max(once, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.list_flush_batch(dst, prepared, out, n, args.rotation, threads)
+    dt = time.perf_counter() - t0
+    ref_lvgl = None
+    try:
+        L = O.ref(args.swap)
+        if L is not None:
+            O.render_scene(L, W, H, 2, 0)
+            k = 50
+            t0 = time.perf_counter()
+            for _ in range(k):
+                L.ref_scene_build(2)   # invalidates the screen again
+                L.ref_scene_refresh()
+            rdt = time.perf_counter() - t0
+            L.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+            ref_lvgl = {"value": round(k * px / rdt / 1e6, 1), "unit": "Mpx/s", "cores": 1, "kind": "reference",
+                        "sample": "the real LVGL builds and renders the same widget scene (rasterisers + blend, no flush "
+                                  "rotation) %d times, %.2f ms per frame" % (k, rdt / k * 1e3)}
+    except Exception as e:
+        ref_lvgl = {"error": str(e)}
+    return {
+        "reference_lvgl": ref_lvgl,
+        "value": round(n * px * reps / dt / 1e6, 1), "unit": "Mpx/s", "cores": threads, "kind": "port",
+        "sample": "%d frames of %dx%d x %d passes, %d descriptors per frame + flush rotation, %.1f s wall on %d threads "
+                  "(OpenMP over frames)" % (n, W, H, reps, len(rec), dt, threads),
+        "gpu_matches_cpu_on_first_frames": ok,
+    }
+
+
 def eighth_gpu(args, step_on, n_px, bpp):
     """The same launch restricted to 32 of the 256 CUs (hipExtStreamCreateWithCUMask), i.e. 1/8 of the GPU's compute.
     The runtime deals CU-mask bits round-robin over the XCDs and rejects a mask that leaves an XCD empty, so the
@@ -166,7 +217,7 @@ def main():
         a8 = lvgpu.synth(lvgpu.SYNTH_MASK_UI if args.mask == "ui" else lvgpu.SYNTH_MASK_UNI, SEED_MASK, first, (n, H, W))
         dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
     swap_bytes = 0 if args.swap else 1
-    blist = None
+    blist, rec = None, None
     if args.workload == "scene":
         assert (W, H) == (480, 320), "the recorded scenes are 480x320"
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -196,7 +247,7 @@ def main():
     torch.cuda.synchronize()
     kernel = lvgpu.last_kernel()
     d_first = dst[:4].cpu().numpy().view("uint16").reshape(-1).copy()
-    o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy() if "flush" in args.workload else None
+    o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy() if ("flush" in args.workload or args.workload == "scene") else None
     for _ in range(max(0, args.warmup - 1)):
         step()
 
@@ -274,6 +325,8 @@ def main():
             res["eighth_gpu"] = eighth
         if world == 1 and not args.no_cpu_baseline and args.workload in ("blend_flush", "blend"):
             res["cpu_baseline"] = cpu_baseline(args, W, H, d_first, o_first)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "scene":
+            res["cpu_baseline"] = cpu_baseline_scene(args, W, H, rec, d_first, o_first)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

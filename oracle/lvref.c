@@ -760,3 +760,31 @@ void lvref_argb_blend_flush_batch(uint16_t * dst, const uint32_t * src, uint16_t
     }
     (void)threads;
 }
+
+/* A display list -- n_items descriptors applied in order -- replayed over n_frames draw buffers of width x height
+ * (OpenMP over frames), each followed by the flush rotation when out != NULL.  The descriptors' buf field is ignored;
+ * their sources and masks are shared by all frames.  This is the CPU side of the bench's scene workload. */
+void lvref_list_flush_batch(uint16_t * dst, const lvref_blend_t * items, int n_items, uint16_t * out, int width, int height,
+                            int n_frames, int rotation, int threads)
+{
+    lvref_area_t full = {0, 0, (int16_t)(width - 1), (int16_t)(height - 1)};
+    size_t px = (size_t)width * height;
+    uint32_t trans_size = (uint32_t)(px / 10);
+#ifdef _OPENMP
+    if(threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static)
+#endif
+    for(int f = 0; f < n_frames; f++) {
+        uint16_t * d = dst + (size_t)f * px;
+        for(int i = 0; i < n_items; i++) {
+            lvref_blend_t b = items[i];
+            b.buf = d;
+            lvref_blend(&b);
+        }
+        if(out) {
+            struct cat_ctx c = {out + (size_t)f * px, 0};
+            lvref_flush(&full, d, rotation, trans_size, width, height, cat_cb, &c);
+        }
+    }
+    (void)threads;
+}

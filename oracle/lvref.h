@@ -97,4 +97,7 @@ void lvref_argb_blend_flush_batch(uint16_t * dst, const uint32_t * src, uint16_t
 #ifdef __cplusplus
 }
 #endif
+void lvref_list_flush_batch(uint16_t * dst, const lvref_blend_t * items, int n_items, uint16_t * out, int width, int height,
+                            int n_frames, int rotation, int threads);
+
 #endif

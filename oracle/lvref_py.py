@@ -98,6 +98,8 @@ def lib():
         L.lvref_image_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.lvref_image_convert.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                           C.c_uint16, C.c_uint16, C.c_uint8]
+        L.lvref_list_flush_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int]
         L.lvref_img_blend.restype = C.c_int
         L.lvref_img_blend.argtypes = [C.c_void_p, Area, Area, Area, C.c_void_p, C.c_int, C.c_uint8, C.c_int, C.c_int]
         L.lvref_flush.restype = C.c_int
@@ -213,6 +215,31 @@ class RecItem(C.Structure):
     """ref_rec_t of oracle/ref_harness.c"""
     _fields_ = [("area", C.c_int16 * 4), ("src", C.POINTER(C.c_uint16)), ("mask", C.POINTER(C.c_uint8)),
                 ("color", C.c_uint16), ("opa", C.c_uint8), ("blend_mode", C.c_uint8)]
+
+
+def prepare_list(items, width, height, swap):
+    """Marshal a display list once: items are dicts area/src/mask/color/opa/blend_mode (as tests/util.load_scene
+    returns them).  Returns an opaque object for list_flush_batch."""
+    arr = (BlendDsc * len(items))()
+    keep = []
+    for i, it in enumerate(items):
+        d = arr[i]
+        d.buf_area = Area(0, 0, width - 1, height - 1)
+        d.clip_area = d.blend_area = d.mask_area = Area.of(it["area"])
+        s = None if it["src"] is None else np.ascontiguousarray(it["src"])
+        m = None if it["mask"] is None else np.ascontiguousarray(it["mask"])
+        keep += [s, m]
+        d.src_buf, d.mask_buf = _p(s), _p(m)
+        d.color, d.opa, d.blend_mode = int(it["color"]), int(it["opa"]), int(it["blend_mode"])
+        d.mask_res, d.swap, d.screen_transp = MASK_RES_CHANGED, swap, 0
+    return arr, keep, width, height
+
+
+def list_flush_batch(dst, prepared, out, n_frames, rotation, threads):
+    """The list applied in order to every frame of dst ([n, H, W] uint16, in place), each frame then flushed with the
+    rotation into out (flat uint16) unless out is None; OpenMP over frames."""
+    arr, _keep, width, height = prepared
+    lib().lvref_list_flush_batch(_p(dst), arr, len(arr), _p(out), width, height, n_frames, rotation, threads)
 
 
 def ref_available(swap=1):
