@@ -276,23 +276,36 @@ struct LaunchRows {
     static int run(const BlendArgs & a, hipStream_t st)
     {
         const uint32_t gmax = ((uint32_t)a.w + 7 + 7) / 8;  // groups per row for the worst row alignment
-        const uint64_t lanes = (uint64_t)gmax * (uint32_t)a.h;
+        uint64_t lanes = (uint64_t)gmax * (uint32_t)a.h;
+        RowsMap map;
+        memset(&map, 0, sizeof(map));
+        if((a.dst_stride % 8) == 0 && (a.dst_fs % 8) == 0) {  // one alignment for every row of every frame
+            const uint32_t off = (uint32_t)((reinterpret_cast<uintptr_t>(a.dst) >> 1) & 7u);
+            map.uniform = 1;
+            map.k_lo = off ? 1u : 0u;
+            map.k_hi = ((uint32_t)a.w + off) / 8;
+            if(map.k_hi < map.k_lo) map.k_hi = map.k_lo = 0;  // no whole group at all: group 0 holds the whole row
+            map.n_whole_row = map.k_hi - map.k_lo;
+            map.edge_lo = (map.k_lo > 0 || map.k_hi == 0) ? 1 : 0;
+            map.edge_hi = (map.k_hi > 0 && map.k_hi * 8 < (uint32_t)a.w + off) ? 1 : 0;
+            lanes = (uint64_t)map.n_whole_row * (uint32_t)a.h + 2ull * (uint32_t)a.h;
+        }
         dim3 grid((uint32_t)((lanes + 255) / 256), std::min<uint32_t>(a.n_frames, 65535));
         // the combinations resolve_blend produces with the normal blend function; everything else decides per pixel
         constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
         const bool normal = a.blend_fn == BF_NORMAL;
         if(normal && a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), 0, st, a, gmax, map);
         else if(normal && a.opa_mode == OM_CONST && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), 0, st, a, gmax, map);
         else if(normal && a.opa_mode == OM_MASK && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), 0, st, a, gmax, map);
         else if(normal && a.opa_mode == OM_FILL_MASK_OPA && SRC == SRC_FILL)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), 0, st, a, gmax, map);
         else if(normal && a.opa_mode == OM_MAP_MASK_OPA && SRC != SRC_FILL && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), 0, st, a, gmax, map);
         else
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), 0, st, a, gmax);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), 0, st, a, gmax, map);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }

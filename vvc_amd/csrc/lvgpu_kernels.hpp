@@ -534,6 +534,29 @@ __device__ __forceinline__ void load_src_unaligned(const void * base, long long 
     }
 }
 
+// source colour (native) and alpha / mask of the pixel at area-relative (x, y) of frame f
+template <int SRC>
+__device__ __forceinline__ void fetch_one_px(const BlendArgs & a, uint32_t f, uint32_t x, uint32_t y, uint32_t & fg, uint32_t & m)
+{
+    const size_t sp = (size_t)y * a.src_stride + x;
+    if(SRC == SRC_RGB565) {
+        uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
+        fg = a.swap ? px_swap16(v) : v;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
+        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+        m = v >> 24;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
+        uint32_t v = p[0] | (p[1] << 8);
+        fg = a.swap ? px_swap16(v) : v;
+        m = p[2];
+    }
+    if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
+}
+
 // one pixel at area-relative (x, y) of frame f, scalar accesses
 template <int SRC>
 __device__ __forceinline__ void blend_one_px(const BlendArgs & a, uint32_t f, uint32_t x, uint32_t y, uint32_t fnb)
@@ -564,14 +587,42 @@ __device__ __forceinline__ void blend_one_px(const BlendArgs & a, uint32_t f, ui
     *dp = (uint16_t)r;
 }
 
+// How k_blend_rows maps lanes to groups (filled in by the launcher).
+struct RowsMap {
+    int uniform;           // 1: rows of all frames share one alignment
+    uint32_t k_lo, k_hi;   // whole groups of a row are k_lo .. k_hi-1
+    uint32_t n_whole_row;  // k_hi - k_lo
+    int edge_lo, edge_hi;  // group 0 / group k_hi is a partial group that holds pixels of the area
+};
+
 // OM: the opacity mode fixed at compile time (the launcher picks it; OM_RUNTIME for the blend modes and anything
 // else) -- this kernel spends its time issuing integer instructions, not waiting for memory.
 template <int SRC, int OM>
-__global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax)
+__global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax, RowsMap map)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t y = idx / gmax, k = idx - y * gmax;
-    if(y >= (uint32_t)a.h) return;
+    uint32_t y, k;
+    if(map.uniform) {
+        // every row of every frame starts at the same position within its 16-byte group, so the launcher knows which
+        // groups are whole: those come first (lanes that only ever take the vector path), the at most two partial
+        // groups per row come last, in wavefronts of their own
+        const uint32_t n_whole = map.n_whole_row * (uint32_t)a.h;
+        if(idx < n_whole) {
+            y = idx / map.n_whole_row;
+            k = map.k_lo + (idx - y * map.n_whole_row);
+        }
+        else {
+            const uint32_t e = idx - n_whole;
+            y = e >> 1;
+            k = (e & 1u) ? map.k_hi : 0u;
+            if(y >= (uint32_t)a.h || !((e & 1u) ? map.edge_hi : map.edge_lo)) return;
+        }
+    }
+    else {
+        y = idx / gmax;
+        k = idx - y * gmax;
+        if(y >= (uint32_t)a.h) return;
+    }
     for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
         uint16_t * row = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride;
         const int off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7u);  // row start within its 16-byte group
@@ -592,9 +643,29 @@ __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax)
                 blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d, sw, mk, y * (uint32_t)a.w + (uint32_t)x_lo, fnb);
         }
         else {
+            // A group that sticks out of the area on one side.  The aligned 16-byte word is read whole (it shares its
+            // page with the pixels that do belong to the area); source and mask are fetched pixel by pixel, for the
+            // area's pixels only and all of them before any arithmetic; only the area's pixels are written back.
+            const uint4 d = *reinterpret_cast<const uint4 *>(row + x_lo);
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+            uint32_t fg[8], m[8];
+#pragma unroll
             for(int j = 0; j < 8; j++) {
                 const int x = x_lo + j;
-                if(x >= 0 && x < a.w) blend_one_px<SRC>(a, f, (uint32_t)x, y, fnb);
+                fg[j] = a.color;
+                m[j] = 0;
+                if(x >= 0 && x < a.w) fetch_one_px<SRC>(a, f, (uint32_t)x, y, fg[j], m[j]);
+            }
+#pragma unroll
+            for(int j = 0; j < 8; j++) {
+                const int x = x_lo + j;
+                if(x >= 0 && x < a.w) {
+                    uint32_t dn = (dw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if(a.swap) dn = px_swap16(dn);
+                    uint32_t r = px_core_s<OM, OM == OM_RUNTIME>(a, dn, fg[j], m[j], y * (uint32_t)a.w + (uint32_t)x, fnb);
+                    if(a.swap) r = px_swap16(r);
+                    row[x] = (uint16_t)r;
+                }
             }
         }
     }
