@@ -557,36 +557,6 @@ __device__ __forceinline__ void fetch_one_px(const BlendArgs & a, uint32_t f, ui
     if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
 }
 
-// one pixel at area-relative (x, y) of frame f, scalar accesses
-template <int SRC>
-__device__ __forceinline__ void blend_one_px(const BlendArgs & a, uint32_t f, uint32_t x, uint32_t y, uint32_t fnb)
-{
-    uint16_t * dp = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride + x;
-    uint32_t d = *dp;
-    if(a.swap) d = px_swap16(d);
-    uint32_t fg = a.color, m = 0;
-    const size_t sp = (size_t)y * a.src_stride + x;
-    if(SRC == SRC_RGB565) {
-        uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
-        fg = a.swap ? px_swap16(v) : v;
-    }
-    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
-        uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
-        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
-        m = v >> 24;
-    }
-    else if(SRC == SRC_ARGB8565) {
-        const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
-        uint32_t v = p[0] | (p[1] << 8);
-        fg = a.swap ? px_swap16(v) : v;
-        m = p[2];
-    }
-    if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
-    uint32_t r = px_core(a, d, fg, m, y * (uint32_t)a.w + x, fnb);
-    if(a.swap) r = px_swap16(r);
-    *dp = (uint16_t)r;
-}
-
 // How k_blend_rows maps lanes to groups (filled in by the launcher).
 struct RowsMap {
     int uniform;           // 1: rows of all frames share one alignment
