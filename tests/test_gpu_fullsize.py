@@ -117,3 +117,50 @@ def test_config5_large_canvas_3840x2160(gpu, oracle):
     oracle.img_blend(d, area, area, area, s, oracle.SRC_ARGB8888, 255, 1, Wc)
     assert np.array_equal(dst[2].cpu().numpy().view(np.uint16), d)
     assert np.array_equal(out[2].cpu().numpy().view(np.uint16).reshape(-1), oracle.flush_frame(d, Wc, Hc, 1))
+
+
+def test_two_host_threads_on_their_own_streams(gpu, oracle):
+    """The C ABI keeps its per-call state (error text, last kernel, staging of display-list tables) per host thread:
+    two threads drive their own streams and buffers at the same time -- single descriptors and display lists -- and
+    both get the oracle's result."""
+    import threading
+    from util import to_dev, to_np
+    W, H, N = 480, 320, 64
+    area = (0, 0, W - 1, H - 1)
+    results = {}
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            stream = torch.cuda.Stream()
+            dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            src = rng.integers(0, 1 << 32, (H, W), dtype=np.uint32)
+            mask = rng.integers(0, 256, (40, 200), dtype=np.uint8)
+            exp = dst.copy()
+            with torch.cuda.stream(stream):
+                d, s, m = to_dev(dst), to_dev(src), to_dev(mask)
+                ctx = gpu.DrawCtx(d, color_16_swap=1)
+                one = gpu.BlendDsc(area, src_buf=s, opa=255, src_format=gpu.SRC_ARGB8888)
+                lst = [gpu.BlendDsc((7 + 3 * i, 5 + 2 * i, 206 + 3 * i, 44 + 2 * i), color=1000 * tid + i, mask_buf=m, opa=200)
+                       for i in range(20)]
+                for _ in range(5):
+                    out = gpu.blend_flush(ctx, one, 1, stream=stream.cuda_stream)
+                    out2 = gpu.blend_list_flush(ctx, lst, 3, stream=stream.cuda_stream)
+                stream.synchronize()
+                got, o2 = to_np(d, np.uint16), to_np(out2, np.uint16).reshape(N, -1)
+            e = exp[0]
+            for _ in range(5):
+                oracle.img_blend(e, area, area, area, src, oracle.SRC_ARGB8888, 255, 1, W)
+                for i in range(20):
+                    a = (7 + 3 * i, 5 + 2 * i, 206 + 3 * i, 44 + 2 * i)
+                    oracle.blend(e, area, area, a, color=1000 * tid + i, mask=mask, opa=200, swap=1)
+            results[tid] = bool(np.array_equal(got[0], e)) and bool(np.array_equal(o2[0], oracle.flush_frame(e, W, H, 3, 0)))
+        except Exception as ex:  # surfaced by the assertion below
+            results[tid] = repr(ex)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert results == {0: True, 1: True}, results
