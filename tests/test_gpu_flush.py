@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3),
-                                   (96, 200), (64, 40), (200, 344), (136, 72), (8, 8)])
+                                   (96, 200), (64, 40), (200, 344), (136, 72), (8, 8), (240, 135), (135, 240), (65, 129)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -19,7 +19,10 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     out = gpu.flush_rotate(to_dev(frames), rot, swap_bytes=swap_bytes)
     fast = W % 8 == 0 and H % 8 == 0
     quarter = ("k_strip" if H % 32 else "k_tile")  # heights off the 32-px grid take the column-strip kernel
-    assert gpu.last_kernel() == ((quarter if rot in (1, 3) else "k_blend_linear") if fast else "k_rotate_generic")
+    if rot in (1, 3):
+        assert gpu.last_kernel() == (quarter if fast else "k_rotate_tile_any")  # the latter: sizes off the 8-pixel grid
+    else:  # a copy / reversal only needs the frame to be a whole number of 8-pixel groups
+        assert gpu.last_kernel() == ("k_blend_linear" if (W * H) % 8 == 0 else "k_rotate_generic")
     got = to_np(out, np.uint16).reshape(N, -1)
     for f in range(N):
         exp = oracle.flush_frame(frames[f], W, H, rot, swap_bytes)

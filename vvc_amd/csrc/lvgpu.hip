@@ -408,6 +408,17 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
         g_last_kernel = "k_blend_linear";
         return LaunchLinear<SRC_COPY>::run(a, st);
     }
+    if(transposing) {
+        const uint32_t tiles_x = (uint32_t)(W + 63) / 64, tiles_y = (uint32_t)(H + 63) / 64;
+        const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y * (uint32_t)n_frames;
+        if(n_tiles <= 0x7FFFFFFFull) {
+            g_last_kernel = "k_rotate_tile_any";
+            hipLaunchKernelGGL(k_rotate_tile_any, dim3((uint32_t)n_tiles), dim3(256), 0, st, in, in_fs, out, out_fs, W, H, rot,
+                               swap_out ? 1 : 0, tiles_x, tiles_x * tiles_y, (uint32_t)n_tiles);
+            HIP_TRY(hipGetLastError());
+            return LVGPU_OK;
+        }
+    }
     g_last_kernel = "k_rotate_generic";
     const uint32_t area = (uint32_t)W * (uint32_t)H;
     dim3 grid((area + 255) / 256, std::min<uint32_t>(n_frames, 65535));

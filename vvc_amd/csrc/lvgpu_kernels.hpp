@@ -902,6 +902,42 @@ __global__ __launch_bounds__(256) void k_rotate_generic(const uint16_t * in, lon
     }
 }
 
+// 90/270-degree rotation of frames whose sizes are not multiples of 8 (e.g. 240x135 panels): a block moves one 64x64
+// tile through LDS so that both the 2-byte loads (along source rows) and the 2-byte stores (along panel rows) are
+// contiguous per wavefront; rows of the LDS tile are padded by one pixel against bank conflicts.
+__global__ __launch_bounds__(256) void k_rotate_tile_any(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
+                                                         int W, int H, int rot, int swap_out, uint32_t tiles_x, uint32_t tpf,
+                                                         uint32_t n_tiles)
+{
+    __shared__ uint16_t t[64][66];
+    const uint32_t b = xcd_remap(blockIdx.x, gridDim.x);
+    if(b >= n_tiles) return;
+    const uint32_t f = b / tpf, tt = b - f * tpf;
+    const int ty = (int)(tt / tiles_x), tx = (int)(tt - (uint32_t)ty * tiles_x);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint16_t * src = in + (long long)f * in_fs;
+    uint16_t * dst = out + (long long)f * out_fs;
+#pragma unroll
+    for(int i = 0; i < 16; i++) {
+        const int r = i * 4 + w, y = ty * 64 + r, x = tx * 64 + l;
+        if(y < H && x < W) {
+            uint32_t v = src[(size_t)y * W + x];
+            t[r][l] = (uint16_t)(swap_out ? px_swap16(v) : v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int i = 0; i < 16; i++) {
+        const int c = i * 4 + w, x = tx * 64 + c;  // source column = panel row
+        const int r = rot == 1 ? 63 - l : l;        // lanes walk the panel row in ascending address order
+        const int y = ty * 64 + r;
+        if(x < W && y < H) {
+            const size_t o = rot == 1 ? (size_t)x * H + (size_t)(H - 1 - y) : (size_t)(W - 1 - x) * H + (size_t)y;
+            dst[o] = t[r][c];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // colour conversion, split, copy, synthetic data, checksum
 // ---------------------------------------------------------------------------------------------------------------
