@@ -27,3 +27,19 @@ def test_c_host_program(gpu, oracle, rot):
     assert int(vals["panel_images"]) == oracle.checksum(panel, 0)
     assert int(vals["bad_clip_rc"]) == -1
     assert "fused" in vals["frames"]
+    # the display-list phase of the example: background + 40 one-row masked fills + a translucent panel, one launch
+    mask = oracle.synth(oracle.SYNTH_MASK_UI, 0x5EED0003, 0, 200 * 40).reshape(40, 200)
+    frames = np.empty((n, H, W), np.uint16)
+    area = (0, 0, W - 1, H - 1)
+    one = np.empty((H, W), np.uint16)
+    oracle.blend(one, area, area, area, color=0x1084, opa=255, swap=1)
+    for r in range(40):
+        row = (37, 50 + r, 236, 50 + r)
+        oracle.blend(one, area, area, row, color=0xE0FF, mask=mask[r:r + 1], opa=230, swap=1)
+    oracle.blend(one, area, area, (100, 20, 400, 300), color=0x00F8, opa=96, swap=1)
+    frames[:] = one  # the opaque background makes every frame the same
+    assert int(vals["list_draw_buffers"]) == oracle.checksum(frames.reshape(-1), 0)
+    pan = np.concatenate([oracle.flush_frame(one, W, H, rot, 0)] * n)
+    assert int(vals["list_panel_images"]) == oracle.checksum(pan, 0)
+    assert vals["list_kernel"] == "k_blend_list(fused)" and int(vals["list_launches"]) == 1
+    assert int(vals["list_steps"]) < 42 * 40  # far fewer steps than items x tiles: the rows are batched
