@@ -224,6 +224,25 @@ int lvgpu_blend_list_plan(const lvgpu_blend_batch_t * geom, const lvgpu_blend_ba
                           int32_t rotation, lvgpu_list_plan_t * plan);
 
 /*
+ * A display list planned once and replayed many times.  lvgpu_list_create does everything lvgpu_blend_list_batch /
+ * lvgpu_blend_list_flush_batch do up to the launch (argument checks, tiling, batching, culling) and leaves the
+ * tables on the device; lvgpu_list_replay is then a single kernel launch that allocates and copies nothing --
+ * for scenes that are drawn over and over (every refresh of a static screen, the same overlay on batch after
+ * batch).  The descriptors' src and mask buffers are referenced, not copied: they must stay where they are.
+ * Only lists that the tile pass takes whole can be compiled (see lvgpu_blend_list_batch); otherwise
+ * LVGPU_ERR_UNSUPPORTED, and the uncompiled entry points remain.  flush != 0: replay also writes the panel images.
+ * lvgpu_list_replay: dst == NULL / n_frames == 0 keep what geom named; another dst must have the same geometry
+ * (buf_area, frame stride) and 16-byte alignment.  out / out_frame_stride are used when the list was created with flush.
+ * There is no counterpart in the reference, whose producers re-issue their descriptors on every refresh.
+ */
+typedef struct lvgpu_list lvgpu_list_t;
+int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, int32_t flush,
+                      int32_t rotation, int32_t swap_bytes, lvgpu_list_t ** list);
+int lvgpu_list_replay(const lvgpu_list_t * list, void * dst, int32_t n_frames, void * out, int64_t out_frame_stride,
+                      void * stream);
+int lvgpu_list_destroy(lvgpu_list_t * list);
+
+/*
  * The transport chunks of the reference's flush callback (src/lv_port.c:466-566): the flushed area is cut into pieces of
  * at most trans_size pixels -- whole source columns for 90/270 degrees (:482-487, :500-521), whole rows otherwise
  * (:488-494, :522-543) -- and each piece is sent to the panel as one rectangle.  Every piece is a contiguous slice of

@@ -240,3 +240,52 @@ def test_list_argb8565_destination(gpu, oracle, swap, W, H, N):
             assert gpu.last_kernel() == "k_blend_list"
         else:
             assert gpu.last_kernel() in ("k_blend_argb_dst", "k_blend_argb_linear")
+
+
+def test_compiled_list_replay(gpu, oracle):
+    """lvgpu_list_create / _replay / _destroy: the golden LVGL scene planned once, replayed (one launch, nothing
+    allocated or copied) over the recorded buffers, over other buffers and over a smaller batch, with the fused flush;
+    a list the tile pass cannot take whole is refused."""
+    import torch
+    fb, items = load_scene(os.path.join(_GOLD, "scene2_f0_swap1.npz"))
+    H, W = fb.shape
+    N = 5
+    rng = np.random.default_rng(31)
+    d = to_dev(rng.integers(0, 65536, (N, H, W), dtype=np.uint16))
+    ctx = gpu.DrawCtx(d, color_16_swap=1)
+    dscs, keep = [], []
+    for it in items:
+        s = None if it["src"] is None else to_dev(np.ascontiguousarray(it["src"]))
+        m = None if it["mask"] is None else to_dev(np.ascontiguousarray(it["mask"]))
+        keep += [s, m]
+        dscs.append(gpu.BlendDsc(it["area"], src_buf=s, color=it["color"], mask_buf=m, opa=it["opa"],
+                                 blend_mode=it["blend_mode"]))
+    bl = gpu.BlendList(ctx, dscs).compile(flush=True, rotation=3)
+    exp_out = oracle.flush_frame(fb, W, H, 3, 0)
+    for rep in range(2):
+        out = bl.replay()
+        assert gpu.last_kernel() == "k_blend_list(fused)"
+        got, o = to_np(d, np.uint16), to_np(out, np.uint16).reshape(N, -1)
+        assert all(np.array_equal(got[f], fb) for f in range(N)) and all(np.array_equal(o[f], exp_out) for f in range(N))
+        d.copy_(to_dev(rng.integers(0, 65536, (N, H, W), dtype=np.uint16)))  # scribble over the buffers between replays
+    other = to_dev(rng.integers(0, 65536, (3, H, W), dtype=np.uint16))         # other buffers, smaller batch
+    before = to_np(d, np.uint16).copy()
+    out = bl.replay(buf=other)
+    assert all(np.array_equal(to_np(other, np.uint16)[f], fb) for f in range(3))
+    assert np.array_equal(to_np(out, np.uint16).reshape(3, -1)[2], exp_out)
+    assert np.array_equal(to_np(d, np.uint16), before), "the recorded buffers must stay untouched"
+    bl.release()
+    # without flush, a translucent element on top
+    bl2 = gpu.BlendList(ctx, dscs[:200]).compile()
+    bl2.replay()
+    assert gpu.last_kernel() == "k_blend_list"
+    bl2.release()
+    # a translucent unmasked fill whose value on black depends on scan order cannot be compiled
+    bad = gpu.BlendList(ctx, [gpu.BlendDsc((0, 0, W - 1, H - 1), color=1), gpu.BlendDsc((3, 3, 40, 40), color=0x00F0, opa=135)])
+    with pytest.raises(gpu.LvgpuError) as ei:
+        bad.compile()
+    assert ei.value.code == -3
+    # nor can a buffer whose width is off the 8-pixel grid
+    d7 = torch.zeros((2, 16, 20), dtype=torch.int16, device="cuda")
+    with pytest.raises(gpu.LvgpuError):
+        gpu.BlendList(gpu.DrawCtx(d7), [gpu.BlendDsc((0, 0, 19, 15), color=1)]).compile()

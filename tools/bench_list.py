@@ -90,8 +90,14 @@ def main():
             _lib.check(L.lvgpu_blend_batch(C.byref(arr[i]), st))
         _lib.check(L.lvgpu_flush_rotate_batch(C.byref(fl), st))
 
+    handle = C.c_void_p()
+    _lib.check(L.lvgpu_list_create(C.byref(geom), arr, len(dscs), 1, 1, 0, C.byref(handle)))
+
+    def run_compiled():
+        _lib.check(L.lvgpu_list_replay(handle, None, 0, out.data_ptr(), H * W, st))
+
     res = {"per_descriptor": float("nan")}
-    for name, fn in (("list", run_list), ("per_descriptor", run_seq))[: 1 if a.only_list else 2]:
+    for name, fn in (("list", run_list), ("compiled_list", run_compiled), ("per_descriptor", run_seq))[: 2 if a.only_list else 3]:
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

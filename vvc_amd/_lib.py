@@ -104,6 +104,10 @@ def lib():
         "lvgpu_flush_chunks": (C.c_int, [C.POINTER(Area), C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.POINTER(FlushChunk), C.c_int32]),
         "lvgpu_blend_list_batch": (C.c_int, [C.POINTER(BlendBatch), C.c_int32, vp]),
+        "lvgpu_list_create": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(vp)]),
+        "lvgpu_list_replay": (C.c_int, [vp, vp, C.c_int32, vp, C.c_int64, vp]),
+        "lvgpu_list_destroy": (C.c_int, [vp]),
         "lvgpu_blend_list_plan": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, C.c_int32, C.c_int32,
                                             C.POINTER(ListPlan)]),
         "lvgpu_blend_list_flush_batch": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, vp, C.c_int64,

@@ -666,80 +666,96 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
     p.bin_start[n_tiles] = (uint32_t)p.steps.size();
 }
 
+// The tables of a plan in one block of memory: steps | items | chunks | bin_start | sel (16-, 8-, 8-, 4-, 4-byte
+// elements).  Returns the block's size; with dest != nullptr also writes it and, given the block's device address,
+// fills the table pointers of `a`.
+size_t pack_tables(const ListPlan & plan, const ListBuilder & lb, uint8_t * dest, const uint8_t * dev, ListArgs * a)
+{
+    const size_t b_steps = plan.steps.size() * sizeof(uint4), b_items = lb.items.size() * sizeof(ListItem),
+                 b_chunks = plan.chunks.size() * sizeof(uint2), b_start = plan.bin_start.size() * 4, b_sel = plan.sel.size() * 4;
+    static_assert(sizeof(ListItem) % 8 == 0, "chunks must stay 8-byte aligned behind the items");
+    if(dest) {
+        uint8_t * w = dest;
+        auto put = [&w](const void * p, size_t n) {
+            if(n) memcpy(w, p, n);
+            w += n;
+        };
+        put(plan.steps.data(), b_steps);
+        put(lb.items.data(), b_items);
+        put(plan.chunks.data(), b_chunks);
+        put(plan.bin_start.data(), b_start);
+        put(plan.sel.data(), b_sel);
+    }
+    if(a) {
+        a->steps = reinterpret_cast<const uint4 *>(dev);
+        a->items = reinterpret_cast<const ListItem *>(dev + b_steps);
+        a->chunks = reinterpret_cast<const uint2 *>(dev + b_steps + b_items);
+        a->bin_start = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks);
+        a->sel = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks + b_start);
+        a->n_sel = (uint32_t)plan.sel.size();
+    }
+    return b_steps + b_items + b_chunks + b_start + b_sel;
+}
+
+// two waves per tile pay off when the batches are large enough to keep 128 lanes busy (LVGL's row-by-row
+// producers: 150+ chunks per batch); lists of many small unrelated items are better off with one
+inline bool plan_is_wide(const lvgpu_list_plan_t & ps)
+{
+    return ps.batch_steps > 0 && (ps.chunks_full + ps.chunks_partial) >= 64 * ps.batch_steps;
+}
+
+int launch_list_kernel(const ListArgs & a, bool argb, bool wide, hipStream_t st)
+{
+    const uint64_t waves = (uint64_t)a.n_sel * a.n_frames;
+    if(waves == 0) return LVGPU_OK;
+    if(waves > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+    if(argb) hipLaunchKernelGGL(k_blend_list_argb, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else if(wide)
+        hipLaunchKernelGGL(k_blend_list<2>, dim3((uint32_t)((waves + ListCfg<2>::TPB - 1) / ListCfg<2>::TPB)),
+                           dim3(ListCfg<2>::BLOCK), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_blend_list<1>, dim3((uint32_t)((waves + ListCfg<1>::TPB - 1) / ListCfg<1>::TPB)),
+                           dim3(ListCfg<1>::BLOCK), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+
 // Launch the accumulated items.  out != nullptr: also write the panel image of every tile.
 int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_frames, int swap, uint16_t * out, long long out_fs,
                 int rot, int swap_out, hipStream_t st)
 {
     static thread_local ListPlan plan;  // keeps its capacity between calls
     build_plan(lb, out != nullptr, plan);
-    const std::vector<uint32_t> & bin_start = plan.bin_start;
-    const std::vector<uint32_t> & sel = plan.sel;
-    const std::vector<uint4> & steps = plan.steps;
-    const std::vector<uint2> & chunks = plan.chunks;
-    if(sel.empty()) {
+    if(plan.sel.empty()) {
         lb.clear();
         return LVGPU_OK;
     }
-    const uint64_t waves = (uint64_t)sel.size() * n_frames;
-    if(waves > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-
-    // one device allocation: steps | items | chunks | bin_start | sel   (16-, 8-, 8-, 4-, 4-byte elements)
-    const size_t b_steps = steps.size() * sizeof(uint4), b_items = lb.items.size() * sizeof(ListItem),
-                 b_chunks = chunks.size() * sizeof(uint2), b_start = bin_start.size() * 4, b_sel = sel.size() * 4;
-    static_assert(sizeof(ListItem) % 8 == 0, "chunks must stay 8-byte aligned behind the items");
-    const size_t blob_bytes = b_steps + b_items + b_chunks + b_start + b_sel;
+    if((uint64_t)plan.sel.size() * n_frames > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+    const size_t blob_bytes = pack_tables(plan, lb, nullptr, nullptr, nullptr);
     uint8_t * host = nullptr;
     int rc_stage = g_stage.acquire(blob_bytes, &host);
     if(rc_stage != LVGPU_OK) return rc_stage;
-    uint8_t * w = host;
-    auto put = [&w](const void * p, size_t n) {
-        if(n) memcpy(w, p, n);
-        w += n;
-    };
-    put(steps.data(), b_steps);
-    put(lb.items.data(), b_items);
-    put(chunks.data(), b_chunks);
-    put(bin_start.data(), b_start);
-    put(sel.data(), b_sel);
     uint8_t * dev = nullptr;
     HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob_bytes, st));
+    ListArgs a;
+    memset(&a, 0, sizeof(a));
+    pack_tables(plan, lb, host, dev, &a);
     HIP_TRY(hipMemcpyAsync(dev, host, blob_bytes, hipMemcpyHostToDevice, st));
     rc_stage = g_stage.release(st);
     if(rc_stage != LVGPU_OK) return rc_stage;
-
-    ListArgs a;
-    memset(&a, 0, sizeof(a));
     a.dst = dst;
     a.dst_fs = dst_fs;
     a.W = lb.W;
     a.H = lb.H;
     a.n_frames = n_frames;
-    a.steps = reinterpret_cast<const uint4 *>(dev);
-    a.items = reinterpret_cast<const ListItem *>(dev + b_steps);
-    a.chunks = reinterpret_cast<const uint2 *>(dev + b_steps + b_items);
-    a.bin_start = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks);
-    a.sel = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks + b_start);
-    a.n_sel = (uint32_t)sel.size();
     a.tiles_x = lb.tiles_x;
     a.swap = swap;
     a.out = out;
     a.out_fs = out_fs;
     a.rot = rot;
     a.swap_out = swap_out;
-    if(lb.argb) hipLaunchKernelGGL(k_blend_list_argb, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, a);
-    else {
-        // two waves per tile pay off when the batches are large enough to keep 128 lanes busy (LVGL's row-by-row
-        // producers: 150+ chunks per batch); lists of many small unrelated items are better off with one
-        const lvgpu_list_plan_t & ps = plan.stats;
-        const bool wide = ps.batch_steps > 0 && (ps.chunks_full + ps.chunks_partial) >= 64 * ps.batch_steps;
-        if(wide)
-            hipLaunchKernelGGL(k_blend_list<2>, dim3((uint32_t)((waves + ListCfg<2>::TPB - 1) / ListCfg<2>::TPB)),
-                               dim3(ListCfg<2>::BLOCK), 0, st, a);
-        else
-            hipLaunchKernelGGL(k_blend_list<1>, dim3((uint32_t)((waves + ListCfg<1>::TPB - 1) / ListCfg<1>::TPB)),
-                               dim3(ListCfg<1>::BLOCK), 0, st, a);
-    }
-    HIP_TRY(hipGetLastError());
+    int rc = launch_list_kernel(a, lb.argb, plan_is_wide(plan.stats), st);
+    if(rc != LVGPU_OK) return rc;
     HIP_TRY(hipFreeAsync(dev, st));
     lb.clear();
     return LVGPU_OK;
@@ -872,6 +888,18 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     if(used_list) g_last_kernel = "k_blend_list";
     return LVGPU_OK;
 }
+
+// A display list planned once and kept on the device (lvgpu_list_create / _replay / _destroy).
+struct CompiledList {
+    uint32_t magic;
+    int device;
+    uint8_t * dev;   // the tables
+    ListArgs a;      // everything but dst / n_frames / out / out_fs, which a replay may set
+    bool argb, wide, flush;
+    void * dst;      // as recorded
+    int n_frames;
+};
+constexpr uint32_t LIST_MAGIC = 0x4C4C5354u;  // "LLST"
 
 }  // namespace
 
@@ -1027,6 +1055,113 @@ int lvgpu_blend_list_flush_batch(const lvgpu_blend_batch_t * geom, const lvgpu_b
                                  int64_t out_frame_stride, int32_t rotation, int32_t swap_bytes, void * stream)
 {
     return run_list(geom, items, n_items, true, out, out_frame_stride, rotation, swap_bytes, (hipStream_t)stream);
+}
+
+int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items, int32_t n_items, int32_t flush,
+                      int32_t rotation, int32_t swap_bytes, lvgpu_list_t ** out_list)
+{
+    g_last_kernel = "";
+    if(out_list == nullptr) return fail(LVGPU_ERR_ARG, "NULL out pointer");
+    *out_list = nullptr;
+    if(n_items < 0 || (n_items > 0 && items == nullptr)) return fail(LVGPU_ERR_ARG, "bad item list");
+    if(geom == nullptr) geom = n_items > 0 ? items : nullptr;
+    if(geom == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
+    if(geom->n_frames <= 0 || geom->dst == nullptr) return fail(LVGPU_ERR_ARG, "geometry needs dst and n_frames > 0");
+    if(flush && (rotation < LVGPU_ROT_NONE || rotation > LVGPU_ROT_270)) return fail(LVGPU_ERR_ARG, "bad rotation %d", rotation);
+    if(aw(geom->buf_area) <= 0 || ah(geom->buf_area) <= 0) return fail(LVGPU_ERR_ARG, "empty buf_area");
+    const int W = aw(geom->buf_area), H = ah(geom->buf_area);
+    const bool argb = geom->dst_argb8565 != 0;
+    if(flush && argb) return fail(LVGPU_ERR_UNSUPPORTED, "flush of an ARGB8565 buffer (the reference flushes lv_color_t only)");
+    const bool tiles_ok = argb ? (W % 16) == 0 && aligned(geom->dst, 16) && (geom->dst_frame_stride * 3) % 16 == 0
+                               : (W % 8) == 0 && aligned(geom->dst, 16) && (geom->dst_frame_stride % 8) == 0;
+    const bool transposing = rotation == LVGPU_ROT_90 || rotation == LVGPU_ROT_270;
+    if(!tiles_ok || (flush && transposing && (H % 8) != 0))
+        return fail(LVGPU_ERR_UNSUPPORTED, "this buffer shape does not take the tile pass; use lvgpu_blend_list_batch");
+    ListBuilder lb(W, H, argb);
+    for(int i = 0; i < n_items; i++) {
+        const lvgpu_blend_batch_t & d = items[i];
+        if(d.dst != geom->dst || d.dst_frame_stride != geom->dst_frame_stride || d.n_frames != geom->n_frames ||
+           memcmp(&d.buf_area, &geom->buf_area, sizeof(lvgpu_area_t)) != 0 || (d.color_16_swap != 0) != (geom->color_16_swap != 0) ||
+           (d.dst_argb8565 != 0) != argb)
+            return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
+        BlendArgs ra;
+        lvgpu_area_t area;
+        int r = resolve_blend(&d, ra, area);
+        if(r < 0) {
+            g_err = "item " + std::to_string(i) + ": " + g_err;
+            return r;
+        }
+        if(r != R_WORK) continue;
+        if(needs_scan_order(ra))
+            return fail(LVGPU_ERR_UNSUPPORTED, "item %d needs a pass over its whole area first (translucent fill whose result "
+                        "on black depends on scan order); use lvgpu_blend_list_batch", i);
+        lb.add(ra, d.src_format, area, geom->buf_area);
+    }
+    ListPlan plan;
+    build_plan(lb, flush != 0, plan);
+    CompiledList * cl = new CompiledList();
+    memset(cl, 0, sizeof(*cl));
+    cl->magic = LIST_MAGIC;
+    const size_t bytes = pack_tables(plan, lb, nullptr, nullptr, nullptr);
+    std::vector<uint8_t> host(bytes);
+    hipError_t e = hipGetDevice(&cl->device);
+    if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cl->dev), bytes ? bytes : 16);
+    if(e == hipSuccess) {
+        pack_tables(plan, lb, host.data(), cl->dev, &cl->a);
+        e = hipMemcpy(cl->dev, host.data(), bytes, hipMemcpyHostToDevice);
+    }
+    if(e != hipSuccess) {
+        if(cl->dev) (void)hipFree(cl->dev);
+        delete cl;
+        return fail(LVGPU_ERR_HIP, "lvgpu_list_create: %s", hipGetErrorString(e));
+    }
+    cl->a.dst_fs = geom->dst_frame_stride;
+    cl->a.W = W;
+    cl->a.H = H;
+    cl->a.tiles_x = lb.tiles_x;
+    cl->a.swap = geom->color_16_swap ? 1 : 0;
+    cl->a.rot = rotation;
+    cl->a.swap_out = swap_bytes ? 1 : 0;
+    cl->argb = argb;
+    cl->wide = plan_is_wide(plan.stats);
+    cl->flush = flush != 0;
+    cl->dst = geom->dst;
+    cl->n_frames = geom->n_frames;
+    *out_list = reinterpret_cast<lvgpu_list_t *>(cl);
+    return LVGPU_OK;
+}
+
+int lvgpu_list_replay(const lvgpu_list_t * list, void * dst, int32_t n_frames, void * out, int64_t out_frame_stride, void * stream)
+{
+    g_last_kernel = "";
+    const CompiledList * cl = reinterpret_cast<const CompiledList *>(list);
+    if(cl == nullptr || cl->magic != LIST_MAGIC) return fail(LVGPU_ERR_ARG, "not a list handle");
+    if(n_frames < 0) return fail(LVGPU_ERR_ARG, "n_frames < 0");
+    ListArgs a = cl->a;
+    a.dst = reinterpret_cast<uint16_t *>(dst ? dst : cl->dst);
+    a.n_frames = (uint32_t)(n_frames ? n_frames : cl->n_frames);
+    if(!aligned(a.dst, 16)) return fail(LVGPU_ERR_ARG, "dst must be 16-byte aligned");
+    if(cl->flush) {
+        if(out == nullptr) return fail(LVGPU_ERR_ARG, "out is NULL");
+        if(!aligned(out, 16) || (out_frame_stride % 8) != 0) return fail(LVGPU_ERR_ARG, "out must be 16-byte aligned, its stride a multiple of 8");
+        a.out = reinterpret_cast<uint16_t *>(out);
+        a.out_fs = out_frame_stride;
+    }
+    int rc = launch_list_kernel(a, cl->argb, cl->wide, (hipStream_t)stream);
+    if(rc == LVGPU_OK) g_last_kernel = cl->flush ? "k_blend_list(fused)" : "k_blend_list";
+    return rc;
+}
+
+int lvgpu_list_destroy(lvgpu_list_t * list)
+{
+    CompiledList * cl = reinterpret_cast<CompiledList *>(list);
+    if(cl == nullptr) return LVGPU_OK;
+    if(cl->magic != LIST_MAGIC) return fail(LVGPU_ERR_ARG, "not a list handle");
+    cl->magic = 0;
+    hipError_t e = hipFree(cl->dev);
+    delete cl;
+    if(e != hipSuccess) return fail(LVGPU_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+    return LVGPU_OK;
 }
 
 int lvgpu_flush_chunks(const lvgpu_area_t * area, int32_t hor_res, int32_t ver_res, int32_t rot, uint32_t trans_size,

@@ -259,6 +259,40 @@ class BlendList:
     def run(self, stream=None):
         check(_lib.lib().lvgpu_blend_list_batch(self.arr, self.n, _stream(stream)))
 
+    def compile(self, flush=False, rotation=0, swap_bytes=0):
+        """Plan the list once and keep its tables on the device (lvgpu_list_create); replay() is then one launch."""
+        self.release()
+        h = C.c_void_p()
+        check(_lib.lib().lvgpu_list_create(C.byref(self.geom), self.arr, self.n, 1 if flush else 0, rotation,
+                                            int(swap_bytes), C.byref(h)))
+        self._handle, self._flush, self._rotation = h, bool(flush), rotation
+        return self
+
+    def replay(self, buf=None, out=None, stream=None):
+        """One launch of the compiled list over buf (default: the context's buffers); returns the panel images when the
+        list was compiled with flush."""
+        b = self.ctx.buf if buf is None else buf
+        n, h, w = b.shape[:3]
+        optr, ofs = None, 0
+        if self._flush:
+            if out is None:
+                shape = (n, w, h) if self._rotation in (LV_DISP_ROT_90, LV_DISP_ROT_270) else (n, h, w)
+                out = torch.empty(shape, dtype=b.dtype, device=b.device)
+            optr, ofs = out.data_ptr(), (out.stride(0) if n > 1 else h * w)
+        check(_lib.lib().lvgpu_list_replay(self._handle, b.data_ptr(), n, optr, ofs, _stream(stream)))
+        return out
+
+    def release(self):
+        if getattr(self, "_handle", None):
+            check(_lib.lib().lvgpu_list_destroy(self._handle))
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     def plan(self, flush=False, rotation=0):
         """What replaying the list costs (lvgpu_list_plan_t as a dict); nothing is drawn."""
         p = _lib.ListPlan()
