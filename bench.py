@@ -230,11 +230,11 @@ def main():
             keep += [s16, m8]
             dscs.append(lvgpu.BlendDsc(r["area"], src_buf=s16, color=r["color"], mask_buf=m8, opa=r["opa"],
                                        blend_mode=r["blend_mode"]))
-        blist = lvgpu.BlendList(ctx, dscs)
+        blist = lvgpu.BlendList(ctx, dscs).compile(flush=True, rotation=rot, swap_bytes=swap_bytes)  # planned once
 
     def step(stream=None):
         if blist is not None:
-            blist.run_flush(rot, swap_bytes=swap_bytes, out=out, stream=stream)
+            blist.replay(out=out, stream=stream)
         elif args.workload.startswith("blend_flush"):
             lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
         elif args.workload.startswith("blend"):
@@ -306,7 +306,7 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {
-                "workload": ("scene: %d LVGL blend descriptors (recorded widget scene) as one display list + flush, "
+                "workload": ("scene: %d LVGL blend descriptors (recorded widget scene) as one compiled display list + flush, "
                              "LV_COLOR_16_SWAP %d, %dx%d logical, rotation %d, %d frames per GPU"
                              % (blist.n, args.swap, W, H, rot * 90, n)) if blist is not None else
                             "%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
