@@ -189,7 +189,9 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * dsc, void * stream
  * are applied), except that an item which needs a whole-area pre-pass (a translucent unmasked fill whose result on
  * black depends on scan order, lv_draw_sw_blend.c:262-283) or a shape the tile kernels do not take (width not a
  * multiple of 8 pixels -- 16 for an ARGB8565 destination --, unaligned dst) is run through the lvgpu_blend_batch
- * path in its place in the order.  items is host memory and may be released when the call returns.
+ * path in its place in the order.  items is host memory and may be released when the call returns.  The tables the
+ * kernel walks are planned on the host at every call (about 0.2 ms for 1600 items; see lvgpu_list_create for lists
+ * that repeat) and travel through a pinned staging buffer that each calling thread keeps for its lifetime.
  */
 int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream);
 
