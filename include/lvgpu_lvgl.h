@@ -144,7 +144,8 @@ void lvgpu_lvgl_set_color_16_swap(int swap);
  * blend (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:103); all of LVGL's callers check the pointer.  A display
  * driver that keeps its own flush_cb must therefore call lvgpu_wait_for_finish(drv->draw_ctx) first thing in it.
  * Code that writes draw_ctx->buf directly between blends, other than through the hooks above, is not supported
- * in this mode.
+ * in this mode.  A display with drv->sw_rotate set (LVGL rotates the draw buffer on the CPU right before flush_cb,
+ * libraries/lvgl/src/core/lv_refr.c:1262-1296, with no hook in between) stays in immediate mode.
  */
 void lvgpu_lvgl_set_deferred(int on);
 

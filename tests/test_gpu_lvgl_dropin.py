@@ -120,3 +120,25 @@ def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot):
         assert np.array_equal(a[4], b[4])
     # keep cfg/cb alive until the display is gone
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+
+
+@pytest.mark.parametrize("lv_rot", [1, 2, 3])
+def test_widget_scene_with_lvgl_own_sw_rotate(world, lv_rot):
+    """LVGL's own software rotation (drv.sw_rotate) on top of the GPU blend: LVGL rotates the draw buffer on the CPU
+    right before it flushes, so the buffer must be complete by then -- also when deferred mode was asked for (such a
+    display stays in immediate mode)."""
+    swap, R, L = world
+    hor, ver = (320, 480) if lv_rot != 2 else (480, 320)
+    flags = 4 | (lv_rot << 3)
+    sw = _render_sw(R, hor, ver, 2, flags)
+    assert len(np.unique(sw)) > 20
+    L.lvgpu_lvgl_reset_stats()
+    assert R.ref_scene_display(hor, ver, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit),
+                               L.lvgpu_draw_ctx_size(), None, None, 0, flags) == 0
+    R.ref_scene_build(2)
+    R.ref_scene_refresh()
+    got = _fb(R, hor, ver)
+    st = Stats()
+    L.lvgpu_lvgl_get_stats(C.byref(st))
+    assert st.blend_gpu > 0 and st.blend_delegated == 0 and st.blend_lists == 0
+    assert np.array_equal(got, sw), "%d pixels differ" % int((got != sw).sum())

@@ -256,7 +256,10 @@ void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_c
     int dev = -1;
     HIP_OR_DIE(hipGetDevice(&dev));  // the calling thread's current device; fails when there is none
     HIP_OR_DIE(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    if(g_deferred) {
+    // LVGL's own software rotation reads the draw buffer on the CPU between rendering and flush_cb
+    // (libraries/lvgl/src/core/lv_refr.c:1262-1296) with no hook in between once wait_for_finish is cleared, so a
+    // display that uses it keeps the immediate mode.
+    if(g_deferred && !drv->sw_rotate) {
         Queue * q = new Queue();
         s->q = q;
         // lv_draw_sw_blend calls wait_for_finish before EVERY blend (lv_draw_sw_blend.c:103), which would submit
