@@ -293,7 +293,7 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "Mpixels/sec batched 320x480 RGB565 blend+rotate; % of HBM peak",
+            "metric": "Mpixels/sec batched 320x480 RGB565 blend+rotate; % of HBM peak at 1/8 GPU",
             "value": round(total_px / dt / 1e6, 1),
             "unit": "Mpx/s",
             "n_gpus": world,
