@@ -18,18 +18,26 @@ os.makedirs(dst, exist_ok=True)
 KERNEL = {"blend_flush": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile"}
 BPP = {"blend_flush": 10, "blend": 8, "rotate": 4}
 traffic = {}
+
+
+def newest(pattern):
+    """gpurun merges every run's files into the same directories (named by process id): take the latest."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 for w, kname in KERNEL.items():
     d = os.path.join(src, w)
     if not os.path.isdir(d):
         continue
-    stats = glob.glob(os.path.join(d, "kt", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(d, "kt", "*", "*_kernel_stats.csv"))
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(dst, "%s_kernel_stats.csv" % w), "w") as f:
             csv.writer(f).writerows(rows)
     vals = {}
     for c in ("fetch", "write"):
-        files = glob.glob(os.path.join(d, c, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(d, c, "*", "*_counter_collection.csv"))
         if not files:
             continue
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0])) if kname in r["Kernel_Name"]]
@@ -52,7 +60,7 @@ if traffic:
 lsrc = os.path.join(src, "list")
 if os.path.isdir(lsrc):
     import collections
-    st = glob.glob(os.path.join(lsrc, "kt", "*", "*_kernel_stats.csv"))
+    st = newest(os.path.join(lsrc, "kt", "*", "*_kernel_stats.csv"))
     if st:
         rows = list(csv.reader(open(st[0])))
         with open(os.path.join(dst, "list_scene2_kernel_stats.csv"), "w") as f:
@@ -60,7 +68,7 @@ if os.path.isdir(lsrc):
     out = {"workload": "display list: golden LVGL scene 2 (1649 descriptors, 432119 drawn px per frame) replayed over 4096 "
                        "frames of 480x320 + fused 90-degree flush", "kernel": "k_blend_list"}
     for c in ("fetch", "write", "sq"):
-        files = glob.glob(os.path.join(lsrc, c, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(lsrc, c, "*", "*_counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)

@@ -586,7 +586,7 @@ uint32_t item_kind(const ListItem & it, bool argb)
 struct ListPlan {
     std::vector<uint32_t> bin_start, sel;
     std::vector<uint4> steps;
-    std::vector<uint2> chunks;
+    std::vector<uint4> chunks;
     lvgpu_list_plan_t stats;
 };
 
@@ -603,7 +603,7 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
     memset(&p.stats, 0, sizeof(p.stats));
     p.stats.tiles = (int32_t)n_tiles;
     p.stats.items_listed = (int32_t)lb.items.size();
-    std::vector<uint2> full, part;
+    std::vector<uint4> full, part;
     for(uint32_t t = 0; t < n_tiles; t++) {
         p.bin_start[t] = (uint32_t)p.steps.size();
         bool ow = false;
@@ -651,8 +651,13 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
                 occ[g] |= rows;
                 const int lo = std::max(x1, g * 8) - g * 8, hi = std::min(x2, g * 8 + 7) - g * 8;
                 const uint32_t pxmask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
-                for(int y = y1; y <= y2; y++)
-                    (pxmask == 0xFFu ? full : part).push_back(make_uint2(id, (uint32_t)y | ((uint32_t)g << 6) | (pxmask << 9)));
+                const int ax = tx0 + g * 8 - it.x1;  // area-relative x of the group's first pixel (may be negative)
+                for(int y = y1; y <= y2; y++) {
+                    const int ay = ty0 + y - it.y1;
+                    (pxmask == 0xFFu ? full : part)
+                        .push_back(make_uint4(id, (uint32_t)y | ((uint32_t)g << 6) | (pxmask << 9),
+                                              (uint32_t)(ay * it.mask_stride + ax), (uint32_t)(ay * it.src_stride + ax)));
+                }
                 p.stats.px_chunks += (int64_t)popcount8(pxmask) * (y2 - y1 + 1);
             }
         }
@@ -666,14 +671,13 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
     p.bin_start[n_tiles] = (uint32_t)p.steps.size();
 }
 
-// The tables of a plan in one block of memory: steps | items | chunks | bin_start | sel (16-, 8-, 8-, 4-, 4-byte
+// The tables of a plan in one block of memory: steps | chunks | items | bin_start | sel (16-, 16-, 8-, 4-, 4-byte
 // elements).  Returns the block's size; with dest != nullptr also writes it and, given the block's device address,
 // fills the table pointers of `a`.
 size_t pack_tables(const ListPlan & plan, const ListBuilder & lb, uint8_t * dest, const uint8_t * dev, ListArgs * a)
 {
     const size_t b_steps = plan.steps.size() * sizeof(uint4), b_items = lb.items.size() * sizeof(ListItem),
-                 b_chunks = plan.chunks.size() * sizeof(uint2), b_start = plan.bin_start.size() * 4, b_sel = plan.sel.size() * 4;
-    static_assert(sizeof(ListItem) % 8 == 0, "chunks must stay 8-byte aligned behind the items");
+                 b_chunks = plan.chunks.size() * sizeof(uint4), b_start = plan.bin_start.size() * 4, b_sel = plan.sel.size() * 4;
     if(dest) {
         uint8_t * w = dest;
         auto put = [&w](const void * p, size_t n) {
@@ -681,17 +685,17 @@ size_t pack_tables(const ListPlan & plan, const ListBuilder & lb, uint8_t * dest
             w += n;
         };
         put(plan.steps.data(), b_steps);
-        put(lb.items.data(), b_items);
         put(plan.chunks.data(), b_chunks);
+        put(lb.items.data(), b_items);
         put(plan.bin_start.data(), b_start);
         put(plan.sel.data(), b_sel);
     }
     if(a) {
         a->steps = reinterpret_cast<const uint4 *>(dev);
-        a->items = reinterpret_cast<const ListItem *>(dev + b_steps);
-        a->chunks = reinterpret_cast<const uint2 *>(dev + b_steps + b_items);
-        a->bin_start = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks);
-        a->sel = reinterpret_cast<const uint32_t *>(dev + b_steps + b_items + b_chunks + b_start);
+        a->chunks = reinterpret_cast<const uint4 *>(dev + b_steps);
+        a->items = reinterpret_cast<const ListItem *>(dev + b_steps + b_chunks);
+        a->bin_start = reinterpret_cast<const uint32_t *>(dev + b_steps + b_chunks + b_items);
+        a->sel = reinterpret_cast<const uint32_t *>(dev + b_steps + b_chunks + b_items + b_start);
         a->n_sel = (uint32_t)plan.sel.size();
     }
     return b_steps + b_items + b_chunks + b_start + b_sel;

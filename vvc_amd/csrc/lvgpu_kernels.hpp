@@ -153,16 +153,52 @@ __device__ __forceinline__ void load_src(const void * base, long long px, uint32
     }
 }
 
+// lv_color_mix over one 8-pixel group for the modes that are nothing but a mix (normal blend function, opacity from
+// opa and/or the mask), with the byte order folded into the data movement: one byte permute takes a stored pixel
+// out of its dword, exchanges its bytes if the build swaps them and spreads it over both halves
+// (lv_color.h:449-450, bg | bg << 16); one more puts two results back side by side in stored order.  Same integer
+// arithmetic as px_mix5, pixel by pixel.
+template <int SRC, int OM, class A>
+__device__ __forceinline__ uint4 blend_group_mix(const A & a, uint4 d, const uint32_t * sw, uint2 mk)
+{
+    constexpr uint32_t SPREAD = 0x07E0F81Fu;
+    const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+    const uint32_t sel_in[2] = {a.swap ? 0x00010001u : 0x01000100u, a.swap ? 0x02030203u : 0x03020302u};
+    const uint32_t sel_out = a.swap ? 0x04050001u : 0x05040100u;
+    uint32_t rw[4];
+#pragma unroll
+    for(int j = 0; j < 8; j += 2) {
+        uint32_t r[2];
+#pragma unroll
+        for(int h = 0; h < 2; h++) {
+            const int p = j + h;
+            const uint32_t b = __builtin_amdgcn_perm(dw[p >> 1], dw[p >> 1], sel_in[h]) & SPREAD;
+            uint32_t f, m = ((p < 4 ? mk.x : mk.y) >> ((p & 3) * 8)) & 0xFFu;
+            if(SRC == SRC_RGB565) f = __builtin_amdgcn_perm(sw[p >> 1], sw[p >> 1], sel_in[h]) & SPREAD;
+            else {
+                uint32_t fg = a.color;
+                src_px<SRC>(sw, p, a.swap, fg, m);
+                f = (fg | (fg << 16)) & SPREAD;
+            }
+            const uint32_t o = OM == OM_CONST ? a.opa : px_opa<OM>(m, a.opa);
+            const uint32_t t = ((((f - b) * ((o + 4u) >> 3)) >> 5) + b) & SPREAD;
+            r[h] = t | (t >> 16);  // the pixel in the low half; the high half is not looked at below
+        }
+        rw[j >> 1] = __builtin_amdgcn_perm(r[1], r[0], sel_out);
+    }
+    return make_uint4(rw[0], rw[1], rw[2], rw[3]);
+}
+
 // Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
 template <int SRC, int OM, bool BLENDED, class A>
 __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
     if(OM == OM_OPAQUE && SRC == SRC_RGB565) return make_uint4(sw[0], sw[1], sw[2], sw[3]);  // same stored format
+    if(!BLENDED && (OM == OM_CONST || OM == OM_MASK || OM == OM_FILL_MASK_OPA || OM == OM_MAP_MASK_OPA))
+        return blend_group_mix<SRC, OM>(a, d, sw, mk);
     uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-    if(a.swap) {
 #pragma unroll
-        for(int i = 0; i < 4; i++) dw[i] = px_swap16x2(dw[i]);
-    }
+    for(int i = 0; i < 4; i++) dw[i] = px_swap16x2_if(dw[i], a.swap);
     uint32_t rw[4];
 #pragma unroll
     for(int j = 0; j < 8; j++) {
@@ -174,10 +210,8 @@ __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint3
         if(j & 1) rw[j >> 1] |= r << 16;
         else rw[j >> 1] = r;
     }
-    if(a.swap) {
 #pragma unroll
-        for(int i = 0; i < 4; i++) rw[i] = px_swap16x2(rw[i]);
-    }
+    for(int i = 0; i < 4; i++) rw[i] = px_swap16x2_if(rw[i], a.swap);
     return make_uint4(rw[0], rw[1], rw[2], rw[3]);
 }
 template <int SRC, class A>

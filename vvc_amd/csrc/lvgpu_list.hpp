@@ -39,7 +39,7 @@ struct ListArgs {
     const ListItem * items;
     const uint32_t * bin_start;  // per tile: first step of the tile in steps; tiles_x*tiles_y + 1 entries
     const uint4 * steps;         // what a wave does to its tile, in list order (ListStep)
-    const uint2 * chunks;        // 8-pixel pieces of small items, grouped into batches (ListChunk)
+    const uint4 * chunks;        // 8-pixel pieces of small items, grouped into batches (ListChunk)
     const uint32_t * sel;        // tiles to process: tile index, bit 31 set = the tile's first item overwrites it whole
     uint32_t n_sel;
     uint32_t tiles_x;
@@ -72,7 +72,8 @@ __device__ __forceinline__ void tile_fence()
 // A step is either one item applied to its whole region of the tile (x = LIST_STEP_ITEM | item index), or a batch of
 // chunks (x = kind, y = first chunk, z = number of whole chunks, w = number of partial chunks, whole ones first).
 // A chunk is one 16-byte group of one tile row touched by one small item: x = item index, y = row | group << 6 |
-// pixel mask << 9.  The chunks of a batch come from consecutive items of the same kind (source format, opacity mode,
+// pixel mask << 9, z / w = where the group's first pixel lies in the item's mask (bytes) / source (pixels), relative
+// to the clipped area's first element (signed: a partial group may start left of the area).  The chunks of a batch come from consecutive items of the same kind (source format, opacity mode,
 // blend function, mask or no mask) that touch pairwise different groups, so they can be applied side by side by the
 // lanes of the wave; that is what turns LVGL's hundreds of one-row descriptors per object into a few wave passes.
 constexpr uint32_t LIST_STEP_ITEM = 0x80000000u;
@@ -108,6 +109,28 @@ __device__ __forceinline__ void list_fetch(const ListItem & it, uint32_t f, int 
         m = p[2];
     }
     if(it.mask) m = it.mask[(long long)f * it.mask_fs + (long long)ay * it.mask_stride + ax];
+}
+
+// The same with the element positions given: si = source pixel index, mi = mask byte index (both include the frame).
+template <int SRC>
+__device__ __forceinline__ void list_fetch_at(const ListItem & it, int swap, long long si, long long mi, uint32_t & fg, uint32_t & m)
+{
+    if(SRC == SRC_RGB565) {
+        const uint32_t v = reinterpret_cast<const uint16_t *>(it.src)[si];
+        fg = swap ? px_swap16(v) : v;
+    }
+    else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(it.src)[si];
+        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
+        m = v >> 24;
+    }
+    else if(SRC == SRC_ARGB8565) {
+        const uint8_t * p = reinterpret_cast<const uint8_t *>(it.src) + si * 3;
+        const uint32_t v = p[0] | (p[1] << 8);
+        fg = swap ? px_swap16(v) : v;
+        m = p[2];
+    }
+    if(it.mask) m = it.mask[mi];
 }
 
 // The part of an item that falls into the wave's tile, in tile-relative pixels; (ox, oy) turns a tile-relative
@@ -255,19 +278,19 @@ template <int SRC, int OM, bool BLENDED, int LNT>
 __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, uint32_t f, int tx, int ty, uint32_t first,
                                            uint32_t n_full, uint32_t n_part, int lane)
 {
-    const uint2 * ch = a.chunks + first;
+    const uint4 * ch = a.chunks + first;
     const uint32_t n = n_full + n_part;
-    uint2 c_next = lane < (int)n ? ch[lane] : make_uint2(0, 0);
+    uint4 c_next = lane < (int)n ? ch[lane] : make_uint4(0, 0, 0, 0);
     for(uint32_t base = 0; base < n; base += LNT) {
         const uint32_t idx = base + (uint32_t)lane;
-        const uint2 c = c_next;
+        const uint4 c = c_next;
         if(idx + LNT < n) c_next = ch[idx + LNT];  // requested now, used in the next pass
         if(idx >= n) continue;
         const ListItem & it = a.items[c.x];
         const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
         const uint32_t pxmask = (c.y >> 9) & 0xFFu;
         const int li = row * 8 + ((g ^ (row >> 3)) & 7);
-        const int ax = tx * LT + g * 8 - it.x1, ay = ty * LT + row - it.y1;
+        const long long mi = (long long)f * it.mask_fs + (int)c.z, si = (long long)f * it.src_fs + (int)c.w;
         LaneView v;
         v.color = it.color;
         v.opa = it.opa;
@@ -278,11 +301,9 @@ __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, ui
         if(idx < n_full) {  // the whole group lies inside the item: vector accesses
             uint32_t sw[SrcWords<SRC>::N];
             uint2 mk = make_uint2(0, 0);
-            if(SRC != SRC_FILL)
-                load_src_unaligned<SRC>(it.src, (long long)f * it.src_fs + (long long)ay * it.src_stride + ax, sw);
+            if(SRC != SRC_FILL) load_src_unaligned<SRC>(it.src, si, sw);
             if(it.mask) {
-                u32x2_a1 m = *reinterpret_cast<const u32x2_a1 *>(it.mask + (long long)f * it.mask_fs +
-                                                                 (long long)ay * it.mask_stride + ax);
+                u32x2_a1 m = *reinterpret_cast<const u32x2_a1 *>(it.mask + mi);
                 mk = make_uint2(m.x, m.y);
             }
             const uint4 d = OM == OM_OPAQUE ? make_uint4(0, 0, 0, 0) : tile4[li];
@@ -295,7 +316,7 @@ __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, ui
             for(int j = 0; j < 8; j++) {
                 if((pxmask >> j) & 1u) {
                     uint32_t fg = v.color, m = 0;
-                    list_fetch<SRC>(it, f, ax + j, ay, fg, m);
+                    list_fetch_at<SRC>(it, v.swap, si + j, mi + j, fg, m);
                     uint32_t dn = (dw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
                     if(v.swap) dn = px_swap16(dn);
                     uint32_t res = px_core_s<OM, BLENDED>(v, dn, fg, m, 0u, 0u);
@@ -545,12 +566,12 @@ template <int SRC>
 __device__ __forceinline__ void argb_list_batch(const ListArgs & a, uint8_t * tile, uint32_t f, int tx, int ty, uint32_t first,
                                                 uint32_t n_full, uint32_t n_part, int lane)
 {
-    const uint2 * ch = a.chunks + first;
+    const uint4 * ch = a.chunks + first;
     const uint32_t n = n_full + n_part;
     for(uint32_t base = 0; base < n; base += 64) {
         const uint32_t idx = base + (uint32_t)lane;
         if(idx >= n) continue;
-        const uint2 c = ch[idx];
+        const uint4 c = ch[idx];
         const ListItem & it = a.items[c.x];
         const int row = (int)(c.y & 63u), g = (int)((c.y >> 6) & 7u);
         const uint32_t pxmask = (c.y >> 9) & 0xFFu;

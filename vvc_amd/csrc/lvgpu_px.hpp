@@ -27,6 +27,12 @@ __device__ __forceinline__ uint32_t px_swap16x2(uint32_t v)  // exchange the byt
 {
     return __builtin_amdgcn_perm(v, v, 0x02030001u);
 }
+// The same under a run-time flag, as one instruction either way: the byte selector is the identity when swap == 0
+// (a branch around the exchange gets if-converted into the exchange plus a select per dword).
+__device__ __forceinline__ uint32_t px_swap16x2_if(uint32_t v, int swap)
+{
+    return __builtin_amdgcn_perm(v, v, swap ? 0x02030001u : 0x03020100u);
+}
 __device__ __forceinline__ uint32_t px_swap16(uint32_t v)    // v < 65536
 {
     return ((v << 8) | (v >> 8)) & 0xFFFFu;
