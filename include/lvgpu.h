@@ -263,6 +263,37 @@ typedef struct {
 int lvgpu_flush_chunks(const lvgpu_area_t * area, int32_t hor_res, int32_t ver_res, int32_t rotation, uint32_t trans_size,
                        lvgpu_flush_chunk_t * out, int32_t max_chunks);
 
+/*
+ * One transport chunk as the reference's AXS15231B panel driver puts it on the bus (panel_axs15231b_draw_bitmap,
+ * src/esp_lcd_axs15231b.c:292-337): the gaps are added to the rectangle (:301-304); CASET carries the column window as
+ * two big-endian 16-bit values, last column inclusive (:307-314); the plain-SPI interface also sends RASET with the row
+ * window (:316-325), the QSPI interface does not; the pixels follow under RAMWR when the chunk starts at panel row 0
+ * and under RAMWRC ("write memory continue") otherwise (:330-334), x_end - x_start times y_end - y_start times
+ * bits_per_pixel / 8 bytes of them (:328-329), unchanged (big-endian RGB565 = what an LV_COLOR_16_SWAP 1 draw buffer
+ * or a swap_bytes flush holds).  cmd is the value the driver hands to esp_lcd_panel_io_tx_param / _tx_color: the
+ * command itself, or for QSPI (opcode << 24) | (command << 8) with opcode 0x02 for parameters and 0x32 for pixels
+ * (tx_param / tx_color, :173-193).  out receives 2 (QSPI) or 3 transactions; the last one is the pixel transfer, whose
+ * data is chunk->n_px pixels starting at chunk->offset_px of the panel image.  Host arithmetic only; a recorder or a
+ * transport on the host replays them in order.  Returns the number of transactions or a negative LVGPU_ERR_*.
+ */
+enum {
+    LVGPU_LCD_CMD_CASET = 0x2A,
+    LVGPU_LCD_CMD_RASET = 0x2B,
+    LVGPU_LCD_CMD_RAMWR = 0x2C,
+    LVGPU_LCD_CMD_RAMWRC = 0x3C
+};
+typedef struct {
+    uint32_t cmd;        /* as handed to the panel IO layer (see above)                                            */
+    uint32_t param_len;  /* 4 for CASET / RASET, 0 for the pixel transfer                                          */
+    uint8_t param[4];
+    int32_t is_color;    /* 1: the pixel transfer                                                                  */
+    int64_t data_offset_px;
+    int64_t data_len;    /* bytes                                                                                  */
+} lvgpu_panel_txn_t;
+
+int lvgpu_axs15231b_transactions(const lvgpu_flush_chunk_t * chunk, int32_t x_gap, int32_t y_gap, int32_t qspi,
+                                 int32_t bits_per_pixel, lvgpu_panel_txn_t out[3]);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Colour conversion (libraries/lvgl/src/misc/lv_color.h)                                                       */
 /* ------------------------------------------------------------------------------------------------------------ */

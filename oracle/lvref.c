@@ -678,6 +678,52 @@ void lvref_flush_frame(const uint16_t * in, uint16_t * out, int W, int H, int ro
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* Panel driver: panel_axs15231b_draw_bitmap, src/esp_lcd_axs15231b.c:292-337                                    */
+/* ------------------------------------------------------------------------------------------------------------ */
+static void panel_tx_param(int qspi, lvref_panel_tx_cb tx, void * user, int lcd_cmd, const uint8_t * param, size_t n)
+{
+    if(qspi) { /* :176-180 */
+        lcd_cmd &= 0xff;
+        lcd_cmd <<= 8;
+        lcd_cmd |= 0x02 << 24; /* LCD_OPCODE_WRITE_CMD, :27 */
+    }
+    tx(user, 0, lcd_cmd, param, n);
+}
+static void panel_tx_color(int qspi, lvref_panel_tx_cb tx, void * user, int lcd_cmd, size_t n)
+{
+    if(qspi) { /* :187-191 */
+        lcd_cmd &= 0xff;
+        lcd_cmd <<= 8;
+        lcd_cmd |= 0x32 << 24; /* LCD_OPCODE_WRITE_COLOR, :29 */
+    }
+    tx(user, 1, lcd_cmd, NULL, n);
+}
+void lvref_axs15231b_draw_bitmap(int x_start, int y_start, int x_end, int y_end, int x_gap, int y_gap, int qspi,
+                                 int fb_bits_per_pixel, lvref_panel_tx_cb tx, void * user)
+{
+    uint8_t p[4];
+    x_start += x_gap; /* :301-304 */
+    x_end += x_gap;
+    y_start += y_gap;
+    y_end += y_gap;
+    p[0] = (x_start >> 8) & 0xFF; /* :307-314 */
+    p[1] = x_start & 0xFF;
+    p[2] = ((x_end - 1) >> 8) & 0xFF;
+    p[3] = (x_end - 1) & 0xFF;
+    panel_tx_param(qspi, tx, user, 0x2A /* LCD_CMD_CASET */, p, 4);
+    if(!qspi) { /* :316-325 */
+        p[0] = (y_start >> 8) & 0xFF;
+        p[1] = y_start & 0xFF;
+        p[2] = ((y_end - 1) >> 8) & 0xFF;
+        p[3] = (y_end - 1) & 0xFF;
+        panel_tx_param(qspi, tx, user, 0x2B /* LCD_CMD_RASET */, p, 4);
+    }
+    size_t len = (size_t)(x_end - x_start) * (y_end - y_start) * fb_bits_per_pixel / 8; /* :328-329 */
+    if(y_start == 0) panel_tx_color(qspi, tx, user, 0x2C /* LCD_CMD_RAMWR */, len);   /* :330-331 */
+    else panel_tx_color(qspi, tx, user, 0x3C /* LCD_CMD_RAMWRC */, len);              /* :332-333 */
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
 /* Synthetic inputs and checksum                                                                                */
 /* ------------------------------------------------------------------------------------------------------------ */
 static inline uint64_t fin64(uint64_t z)

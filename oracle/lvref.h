@@ -85,6 +85,14 @@ int lvref_flush(const lvref_area_t * area, const uint16_t * color_map, int rotat
 /* Same pixels as the concatenation of lvref_flush's chunks for one area, written to out (width*height px). */
 void lvref_flush_frame(const uint16_t * in, uint16_t * out, int width, int height, int rotation, int swap_bytes);
 
+/* ---- panel driver (src/esp_lcd_axs15231b.c:173-193, 292-337): what one draw_bitmap hands to the panel IO layer.
+ * tx stands in for esp_lcd_panel_io_tx_param (is_color 0) / esp_lcd_panel_io_tx_color (is_color 1); size in bytes.
+ * Parity unpinned: the driver needs ESP-IDF headers that are not in the reference tree, so it cannot be compiled
+ * here; this is a line-by-line restatement. ---- */
+typedef void (*lvref_panel_tx_cb)(void * user, int is_color, int lcd_cmd, const uint8_t * param, size_t size);
+void lvref_axs15231b_draw_bitmap(int x_start, int y_start, int x_end, int y_end, int x_gap, int y_gap, int qspi,
+                                 int fb_bits_per_pixel, lvref_panel_tx_cb tx, void * user);
+
 /* ---- synthetic inputs / checksum (shared definition with the GPU library's generator) ---- */
 void lvref_synth(void * out, int kind, uint64_t seed, uint64_t first_index, size_t count);
 uint64_t lvref_checksum(const void * in, int elem_bytes, uint64_t first_index, size_t count);

@@ -105,6 +105,8 @@ def lib():
         L.lvref_flush.restype = C.c_int
         L.lvref_flush.argtypes = [C.POINTER(Area), C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p]
+        L.lvref_axs15231b_draw_bitmap.restype = None
+        L.lvref_axs15231b_draw_bitmap.argtypes = [C.c_int] * 8 + [C.c_void_p, C.c_void_p]
         L.lvref_flush_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.lvref_synth.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_size_t]
         L.lvref_checksum.restype = C.c_uint64
@@ -178,6 +180,22 @@ def flush(area, color_map, rotation, trans_size, hor_res, ver_res):
     cbo = _CB(cb)
     lib().lvref_flush(C.byref(a), _p(color_map), rotation, trans_size, hor_res, ver_res, C.cast(cbo, C.c_void_p), None)
     return chunks
+
+
+_TX = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_size_t)
+
+
+def axs15231b_draw_bitmap(x_start, y_start, x_end, y_end, x_gap=0, y_gap=0, qspi=True, bits_per_pixel=16):
+    """The restated panel driver's draw_bitmap: [(is_color, lcd_cmd, param bytes, size)] as handed to the IO layer."""
+    txs = []
+
+    def tx(_user, is_color, cmd, param, size):
+        txs.append((is_color, cmd & 0xFFFFFFFF, b"" if is_color else bytes(param[:size]), size))
+
+    cbo = _TX(tx)
+    lib().lvref_axs15231b_draw_bitmap(x_start, y_start, x_end, y_end, x_gap, y_gap, 1 if qspi else 0, bits_per_pixel,
+                                      C.cast(cbo, C.c_void_p), None)
+    return txs
 
 
 def flush_frame(inp, W, H, rotation, swap_bytes=0):

@@ -207,6 +207,34 @@ def test_flush_chunks_match_the_restated_flush_callback(oracle):
         lvgpu.flush_chunks((0, 0, 99, 9), 100, 10, 7, 500)    # bad rotation
 
 
+def test_panel_transactions_match_the_restated_panel_driver(oracle):
+    """lvgpu_axs15231b_transactions against the oracle's restatement of panel_axs15231b_draw_bitmap
+    (src/esp_lcd_axs15231b.c:292-337; parity unpinned -- the driver needs ESP-IDF headers the reference tree does not
+    hold) for every transport chunk of a flushed frame, plus the known answer for the firmware's geometry: ten QSPI
+    chunks of 48 panel rows, column window 0..319, RAMWR for the first and RAMWRC for the rest."""
+    from vvc_amd import lvgpu
+    for rot in (0, 1, 2, 3):
+        for (xg, yg, qspi, bpp) in [(0, 0, True, 16), (0, 0, False, 16), (3, 5, True, 16), (2, 0, False, 24)]:
+            for ch in lvgpu.flush_chunks((0, 0, 479, 319), 480, 320, rot, 15360):
+                got = lvgpu.axs15231b_transactions(ch, xg, yg, qspi, bpp)
+                exp = oracle.axs15231b_draw_bitmap(ch[0], ch[1], ch[2], ch[3], xg, yg, qspi, bpp)
+                assert len(got) == len(exp) == (2 if qspi else 3)
+                for g, e in zip(got, exp):
+                    assert (g[0], g[1], g[2]) == (e[0], e[1], e[2]), (rot, ch, g, e)
+                    if g[0]:
+                        assert g[3] == ch[4] and g[4] == e[3] == ch[5] * bpp // 8
+    chunks = lvgpu.flush_chunks((0, 0, 479, 319), 480, 320, 1, 15360)
+    assert len(chunks) == 10
+    for k, ch in enumerate(chunks):
+        t = lvgpu.axs15231b_transactions(ch)
+        assert t[0] == (0, 0x02002A00, bytes([0, 0, 0x01, 0x3F]), 0, 0)
+        assert t[1] == (1, 0x32002C00 if k == 0 else 0x32003C00, b"", k * 15360, 30720)
+    with pytest.raises(lvgpu.LvgpuError):
+        lvgpu.axs15231b_transactions((5, 0, 5, 10, 0, 0))      # empty rectangle: the driver asserts
+    with pytest.raises(lvgpu.LvgpuError):
+        lvgpu.axs15231b_transactions(chunks[0], bits_per_pixel=12)
+
+
 def _plan_of_scene(path, W=480, H=320, flush=1):
     """lvgpu_blend_list_plan on a golden display list; the pointers are placeholders (the plan never touches memory)."""
     from util import load_scene

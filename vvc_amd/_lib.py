@@ -103,6 +103,8 @@ def lib():
         "lvgpu_blend_flush_batch": (C.c_int, [C.POINTER(BlendFlushBatch), vp]),
         "lvgpu_flush_chunks": (C.c_int, [C.POINTER(Area), C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.POINTER(FlushChunk), C.c_int32]),
+        "lvgpu_axs15231b_transactions": (C.c_int, [C.POINTER(FlushChunk), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                   C.POINTER(PanelTxn)]),
         "lvgpu_blend_list_batch": (C.c_int, [C.POINTER(BlendBatch), C.c_int32, vp]),
         "lvgpu_list_create": (C.c_int, [C.POINTER(BlendBatch), C.POINTER(BlendBatch), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.POINTER(vp)]),
@@ -163,6 +165,12 @@ class FlushChunk(C.Structure):
     """lvgpu_flush_chunk_t"""
     _fields_ = [("x_start", C.c_int32), ("y_start", C.c_int32), ("x_end", C.c_int32), ("y_end", C.c_int32),
                 ("offset_px", C.c_int64), ("n_px", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PanelTxn(C.Structure):
+    """lvgpu_panel_txn_t"""
+    _fields_ = [("cmd", C.c_uint32), ("param_len", C.c_uint32), ("param", C.c_uint8 * 4), ("is_color", C.c_int32),
+                ("data_offset_px", C.c_int64), ("data_len", C.c_int64)]
 
 
 class LvgpuError(RuntimeError):

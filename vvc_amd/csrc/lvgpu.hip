@@ -1233,6 +1233,37 @@ int lvgpu_flush_chunks(const lvgpu_area_t * area, int32_t hor_res, int32_t ver_r
     return n_chunks;
 }
 
+int lvgpu_axs15231b_transactions(const lvgpu_flush_chunk_t * chunk, int32_t x_gap, int32_t y_gap, int32_t qspi,
+                                 int32_t bits_per_pixel, lvgpu_panel_txn_t out[3])
+{
+    if(chunk == nullptr || out == nullptr) return fail(LVGPU_ERR_ARG, "NULL argument");
+    if(bits_per_pixel != 16 && bits_per_pixel != 24) return fail(LVGPU_ERR_ARG, "bits_per_pixel %d (16 or 24)", bits_per_pixel);
+    if(!(chunk->x_start < chunk->x_end && chunk->y_start < chunk->y_end))  // the driver asserts this (:297-298)
+        return fail(LVGPU_ERR_ARG, "start position must be smaller than end position");
+    const int xs = chunk->x_start + x_gap, xe = chunk->x_end + x_gap;
+    const int ys = chunk->y_start + y_gap, ye = chunk->y_end + y_gap;
+    auto window = [&](lvgpu_panel_txn_t & t, uint32_t cmd, int from, int to_excl) {
+        t = lvgpu_panel_txn_t{};
+        t.cmd = qspi ? (0x02u << 24) | (cmd << 8) : cmd;
+        t.param_len = 4;
+        t.param[0] = (uint8_t)((from >> 8) & 0xFF);
+        t.param[1] = (uint8_t)(from & 0xFF);
+        t.param[2] = (uint8_t)(((to_excl - 1) >> 8) & 0xFF);
+        t.param[3] = (uint8_t)((to_excl - 1) & 0xFF);
+    };
+    int n = 0;
+    window(out[n++], LVGPU_LCD_CMD_CASET, xs, xe);
+    if(!qspi) window(out[n++], LVGPU_LCD_CMD_RASET, ys, ye);
+    lvgpu_panel_txn_t & c = out[n++];
+    c = lvgpu_panel_txn_t{};
+    const uint32_t cmd = ys == 0 ? LVGPU_LCD_CMD_RAMWR : LVGPU_LCD_CMD_RAMWRC;
+    c.cmd = qspi ? (0x32u << 24) | (cmd << 8) : cmd;
+    c.is_color = 1;
+    c.data_offset_px = chunk->offset_px;
+    c.data_len = (int64_t)(xe - xs) * (ye - ys) * bits_per_pixel / 8;
+    return n;
+}
+
 int lvgpu_color_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap, void * stream)
 {
     if(n == 0) return LVGPU_OK;

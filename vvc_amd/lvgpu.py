@@ -226,6 +226,15 @@ def flush_chunks(area, hor_res, ver_res, rotation, trans_size):
     return [(c.x_start, c.y_start, c.x_end, c.y_end, c.offset_px, c.n_px) for c in arr[:n]]
 
 
+def axs15231b_transactions(chunk, x_gap=0, y_gap=0, qspi=True, bits_per_pixel=16):
+    """What the reference's panel driver hands to the panel IO layer for one transport chunk (a tuple from
+    flush_chunks), src/esp_lcd_axs15231b.c:292-337, as [(is_color, cmd, param bytes, data_offset_px, data_len)]."""
+    c = _lib.FlushChunk(*chunk, 0)
+    out = (_lib.PanelTxn * 3)()
+    n = check_count(_lib.lib().lvgpu_axs15231b_transactions(C.byref(c), x_gap, y_gap, 1 if qspi else 0, bits_per_pixel, out))
+    return [(t.is_color, t.cmd, bytes(t.param[:t.param_len]), t.data_offset_px, t.data_len) for t in out[:n]]
+
+
 def check_count(rc):
     if rc < 0:
         raise LvgpuError(rc, _lib.lib().lvgpu_last_error().decode())
