@@ -235,6 +235,8 @@ int lvgpu_blend_list_plan(const lvgpu_blend_batch_t * geom, const lvgpu_blend_ba
  * LVGPU_ERR_UNSUPPORTED, and the uncompiled entry points remain.  flush != 0: replay also writes the panel images.
  * lvgpu_list_replay: dst == NULL / n_frames == 0 keep what geom named; another dst must have the same geometry
  * (buf_area, frame stride) and 16-byte alignment.  out / out_frame_stride are used when the list was created with flush.
+ * A list belongs to the device that was current when it was created; replaying it with another device current is
+ * LVGPU_ERR_ARG.
  * There is no counterpart in the reference, whose producers re-issue their descriptors on every refresh.
  */
 typedef struct lvgpu_list lvgpu_list_t;

@@ -27,11 +27,22 @@ def main():
     L.lvgpu_lvgl_bind(addr(R.lv_draw_sw_init_ctx), addr(R.lv_draw_sw_blend_basic), addr(R.lv_disp_flush_ready))
     L.lvgpu_lvgl_set_color_16_swap(1)
     frames = {}
-    for mode in ("lvgl_sw", "gpu_immediate", "gpu_deferred"):
-        L.lvgpu_lvgl_set_deferred(1 if mode == "gpu_deferred" else 0)
+
+    class FlushCfg(C.Structure):  # lvgpu_flush_cfg_t
+        _fields_ = [("sw_rotate", C.c_int32), ("trans_size", C.c_uint32), ("swap_bytes", C.c_int32),
+                    ("draw_bitmap", C.c_void_p), ("draw_wait", C.c_void_p), ("user", C.c_void_p)]
+
+    sink = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16))(lambda *a: None)
+    cfg = FlushCfg(1, W * H // 10, 0, C.cast(sink, C.c_void_p), None, None)
+    modes = ["lvgl_sw", "gpu_immediate", "gpu_deferred"] + ([] if flags & 2 else ["gpu_deferred+flush_cb"])
+    for mode in modes:
+        L.lvgpu_lvgl_set_deferred(1 if mode.startswith("gpu_deferred") else 0)
         R.ref_scene_set_pre_flush(addr(L.lvgpu_wait_for_finish) if mode == "gpu_deferred" else None)
         if mode == "lvgl_sw":
             R.ref_scene_display(W, H, None, None, 0, None, None, 1, flags)
+        elif mode == "gpu_deferred+flush_cb":  # blend and 90-degree flush both through the plug-in, ten chunks to a sink
+            R.ref_scene_display(W, H, addr(L.lvgpu_draw_ctx_init), addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                                addr(L.lvgpu_flush_cb), C.addressof(cfg), 1, flags)
         else:
             R.ref_scene_display(W, H, addr(L.lvgpu_draw_ctx_init), addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
                                 None, None, 1, flags)
@@ -42,8 +53,9 @@ def main():
             R.ref_scene_build(scene)   # invalidates the screen again
             R.ref_scene_refresh()
         dt = (time.perf_counter() - t0) / reps
-        frames[mode] = np.ctypeslib.as_array(C.cast(R.ref_scene_fb(), C.POINTER(C.c_uint8)), shape=(H * W * bpp,)).copy()
-        print("%-14s %8.2f ms per refresh of scene %d (%dx%d, flags %d)" % (mode, dt * 1e3, scene, W, H, flags), flush=True)
+        fb = R.ref_scene_draw_buf() if mode.endswith("flush_cb") else R.ref_scene_fb()  # no capture with a foreign flush_cb
+        frames[mode] = np.ctypeslib.as_array(C.cast(fb, C.POINTER(C.c_uint8)), shape=(H * W * bpp,)).copy()
+        print("%-22s %8.2f ms per refresh of scene %d (%dx%d, flags %d)" % (mode, dt * 1e3, scene, W, H, flags), flush=True)
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
     R.ref_scene_set_pre_flush(None)
     print("identical frames:", all(np.array_equal(frames["lvgl_sw"], v) for v in frames.values()))

@@ -90,7 +90,7 @@ def test_widget_scene_through_gpu_blend(world, scene, res, flags, request):
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
-def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot):
+def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot, request):
     """Both plug-in points: GPU blend + lvgpu_flush_cb; the sink receives the reference's transport chunks."""
     swap, R, L = world
     w, h = 480, 320
@@ -111,6 +111,11 @@ def test_widget_scene_through_gpu_blend_and_flush(world, oracle, rot):
     st = Stats()
     L.lvgpu_lvgl_get_stats(C.byref(st))
     assert st.flush_gpu >= 1 and st.blend_delegated == 0
+    draw_buf = np.ctypeslib.as_array(C.cast(R.ref_scene_draw_buf(), C.POINTER(C.c_uint16)), shape=(h * w,))
+    assert np.array_equal(draw_buf, sw)  # LVGL's draw buffer itself is complete as well
+    if request.node.callspec.params["world"][1]:
+        # deferred mode flushing the whole buffer: the launch that draws the queue also writes the panel image
+        assert L.lvgpu_last_kernel() == b"k_blend_list(fused)"
     # what the restated reference callback would have sent for the software-rendered frame
     exp = oracle.flush((0, 0, w - 1, h - 1), sw, rot, w * h // 10, w, h)
     last = chunks[-len(exp):]  # the last refresh

@@ -744,9 +744,12 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     ListArgs a;
     memset(&a, 0, sizeof(a));
     pack_tables(plan, lb, host, dev, &a);
-    HIP_TRY(hipMemcpyAsync(dev, host, blob_bytes, hipMemcpyHostToDevice, st));
-    rc_stage = g_stage.release(st);
-    if(rc_stage != LVGPU_OK) return rc_stage;
+    const hipError_t e_copy = hipMemcpyAsync(dev, host, blob_bytes, hipMemcpyHostToDevice, st);
+    if(e_copy == hipSuccess) rc_stage = g_stage.release(st);
+    if(e_copy != hipSuccess || rc_stage != LVGPU_OK) {
+        (void)hipFreeAsync(dev, st);
+        return e_copy != hipSuccess ? fail(LVGPU_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e_copy)) : rc_stage;
+    }
     a.dst = dst;
     a.dst_fs = dst_fs;
     a.W = lb.W;
@@ -758,10 +761,11 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     a.out_fs = out_fs;
     a.rot = rot;
     a.swap_out = swap_out;
-    int rc = launch_list_kernel(a, lb.argb, plan_is_wide(plan.stats), st);
-    if(rc != LVGPU_OK) return rc;
-    HIP_TRY(hipFreeAsync(dev, st));
+    const int rc = launch_list_kernel(a, lb.argb, plan_is_wide(plan.stats), st);
+    const hipError_t e_free = hipFreeAsync(dev, st);  // in stream order: after the kernel has read the tables
     lb.clear();
+    if(rc != LVGPU_OK) return rc;
+    if(e_free != hipSuccess) return fail(LVGPU_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e_free));
     return LVGPU_OK;
 }
 
@@ -1141,6 +1145,9 @@ int lvgpu_list_replay(const lvgpu_list_t * list, void * dst, int32_t n_frames, v
     const CompiledList * cl = reinterpret_cast<const CompiledList *>(list);
     if(cl == nullptr || cl->magic != LIST_MAGIC) return fail(LVGPU_ERR_ARG, "not a list handle");
     if(n_frames < 0) return fail(LVGPU_ERR_ARG, "n_frames < 0");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if(cur != cl->device) return fail(LVGPU_ERR_ARG, "the list lives on device %d, the current device is %d", cl->device, cur);
     ListArgs a = cl->a;
     a.dst = reinterpret_cast<uint16_t *>(dst ? dst : cl->dst);
     a.n_frames = (uint32_t)(n_frames ? n_frames : cl->n_frames);

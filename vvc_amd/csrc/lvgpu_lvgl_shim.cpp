@@ -124,8 +124,16 @@ void flush_ready(lvgpu_lv_disp_drv_t * drv)
     }
 }
 
-// Submit the queue: draw buffer to the device, the whole list in one call, draw buffer back.
-void submit(ShimCtx * s)
+// What lvgpu_flush_cb wants from a submit that happens on its behalf: the panel image of the whole draw buffer.
+struct FlushReq {
+    void * d_out;      // device staging for the panel image
+    uint16_t * panel;  // pinned host memory that receives it
+    int rot, swap_bytes;
+};
+
+// Submit the queue: draw buffer to the device, the whole list in one call, draw buffer back.  With fr the same
+// launch also writes the rotated panel image (the tiles are flushed from on-chip memory) and it comes back too.
+void submit(ShimCtx * s, const FlushReq * fr = nullptr)
 {
     Queue * q = s->q;
     if(q == nullptr || q->items.empty()) return;
@@ -167,13 +175,16 @@ void submit(ShimCtx * s)
         b.color_16_swap = (uint8_t)g_swap;
         b.dst_argb8565 = q->transp ? 1 : 0;
     }
-    int rc = lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
+    const int rc = fr ? lvgpu_blend_list_flush_batch(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr->d_out,
+                                                     (int64_t)W * H, fr->rot, fr->swap_bytes, st)
+                      : lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
     if(rc != LVGPU_OK) {
-        fprintf(stderr, "lvgpu: lvgpu_blend_list_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+        fprintf(stderr, "lvgpu: drawing the queued display list failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
         g_errors++;
         abort();
     }
     HIP_OR_DIE(hipMemcpyAsync(q->buf, q->d_fb, fb_bytes, hipMemcpyDeviceToHost, st));
+    if(fr) HIP_OR_DIE(hipMemcpyAsync(fr->panel, fr->d_out, fb_bytes, hipMemcpyDeviceToHost, st));
     HIP_OR_DIE(hipStreamSynchronize(st));
     q->items.clear();
     q->arena.clear();
@@ -452,13 +463,14 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
         fprintf(stderr, "lvgpu_flush_cb: drv->user_data must point to a lvgpu_flush_cfg_t with a draw_bitmap sink\n");
         abort();
     }
-    // deferred mode: the queued blends are drawn now (only a context this library initialised carries a queue)
-    if(drv->draw_ctx && drv->draw_ctx_init == lvgpu_draw_ctx_init) lvgpu_wait_for_finish(drv->draw_ctx);
+    // only a context this library initialised carries a queue (deferred mode)
+    ShimCtx * s = (drv->draw_ctx && drv->draw_ctx_init == lvgpu_draw_ctx_init) ? shim_of(drv->draw_ctx) : nullptr;
     const int x_start = area->x1, x_end = area->x2, y_start = area->y1, y_end = area->y2;
     const int W = x_end - x_start + 1, H = y_end - y_start + 1;
     const int rot = cfg->sw_rotate;
 
     if(cfg->trans_size == 0) {  // src/lv_port.c:568-570
+        if(s) lvgpu_wait_for_finish(drv->draw_ctx);  // the queued blends are drawn now
         cfg->draw_bitmap(cfg->user, x_start, y_start, x_end + 1, y_end + 1, color_p);
         flush_ready(drv);
         return;
@@ -488,23 +500,36 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
     }
     void *d_in = stg.d_in, *d_out = stg.d_out;
     uint16_t * panel = stg.panel;
-    HIP_OR_DIE(hipMemcpy(d_in, color_p, px * 2, hipMemcpyHostToDevice));
-    lvgpu_flush_batch_t f;
-    memset(&f, 0, sizeof(f));
-    f.in = d_in;
-    f.out = d_out;
-    f.in_frame_stride = f.out_frame_stride = (int64_t)px;
-    f.width = W;
-    f.height = H;
-    f.rotation = rot;
-    f.swap_bytes = cfg->swap_bytes;
-    f.n_frames = 1;
-    int rc = lvgpu_flush_rotate_batch(&f, nullptr);
-    if(rc != LVGPU_OK) {
-        fprintf(stderr, "lvgpu: lvgpu_flush_rotate_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
-        abort();
+    // Deferred mode, the whole draw buffer is flushed (full_refresh, the reference's configuration, src/lv_port.c:242)
+    // and it is the buffer the queue draws into: the launch that draws the queue writes the panel image as well, and
+    // the buffer travels to the device once instead of twice.
+    Queue * q = s ? s->q : nullptr;
+    const bool fused = q && !q->items.empty() && !q->transp && q->buf == (void *)color_p && q->buf_area.x1 == x_start &&
+                       q->buf_area.y1 == y_start && q->buf_area.x2 == x_end && q->buf_area.y2 == y_end;
+    if(fused) {
+        const FlushReq fr{d_out, panel, rot, cfg->swap_bytes};
+        submit(s, &fr);
     }
-    HIP_OR_DIE(hipMemcpy(panel, d_out, px * 2, hipMemcpyDeviceToHost));
+    else {
+        if(s) lvgpu_wait_for_finish(drv->draw_ctx);  // the queued blends are drawn now
+        HIP_OR_DIE(hipMemcpy(d_in, color_p, px * 2, hipMemcpyHostToDevice));
+        lvgpu_flush_batch_t f;
+        memset(&f, 0, sizeof(f));
+        f.in = d_in;
+        f.out = d_out;
+        f.in_frame_stride = f.out_frame_stride = (int64_t)px;
+        f.width = W;
+        f.height = H;
+        f.rotation = rot;
+        f.swap_bytes = cfg->swap_bytes;
+        f.n_frames = 1;
+        int rc = lvgpu_flush_rotate_batch(&f, nullptr);
+        if(rc != LVGPU_OK) {
+            fprintf(stderr, "lvgpu: lvgpu_flush_rotate_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+            abort();
+        }
+        HIP_OR_DIE(hipMemcpy(panel, d_out, px * 2, hipMemcpyDeviceToHost));
+    }
 
     // Hand the panel image to the sink in the reference's transport chunks (src/lv_port.c:466-566): same
     // rectangles, same order.  Each chunk is a contiguous slice of the rotated image.
