@@ -587,6 +587,7 @@ struct ListPlan {
     std::vector<uint32_t> bin_start, sel;
     std::vector<uint4> steps;
     std::vector<uint4> chunks;
+    std::vector<uint4> full, part;  // the batch being collected (kept here so that their capacity survives)
     lvgpu_list_plan_t stats;
 };
 
@@ -603,7 +604,9 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
     memset(&p.stats, 0, sizeof(p.stats));
     p.stats.tiles = (int32_t)n_tiles;
     p.stats.items_listed = (int32_t)lb.items.size();
-    std::vector<uint4> full, part;
+    std::vector<uint4> &full = p.full, &part = p.part;
+    full.clear();
+    part.clear();
     for(uint32_t t = 0; t < n_tiles; t++) {
         p.bin_start[t] = (uint32_t)p.steps.size();
         bool ow = false;
@@ -652,13 +655,16 @@ void build_plan(const ListBuilder & lb, bool all_tiles, ListPlan & p)
                 const int lo = std::max(x1, g * 8) - g * 8, hi = std::min(x2, g * 8 + 7) - g * 8;
                 const uint32_t pxmask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
                 const int ax = tx0 + g * 8 - it.x1;  // area-relative x of the group's first pixel (may be negative)
-                for(int y = y1; y <= y2; y++) {
-                    const int ay = ty0 + y - it.y1;
-                    (pxmask == 0xFFu ? full : part)
-                        .push_back(make_uint4(id, (uint32_t)y | ((uint32_t)g << 6) | (pxmask << 9),
-                                              (uint32_t)(ay * it.mask_stride + ax), (uint32_t)(ay * it.src_stride + ax)));
-                }
-                p.stats.px_chunks += (int64_t)popcount8(pxmask) * (y2 - y1 + 1);
+                const int ay0 = ty0 + y1 - it.y1, n_rows = y2 - y1 + 1;
+                std::vector<uint4> & v = pxmask == 0xFFu ? full : part;
+                const size_t at = v.size();
+                v.resize(at + (size_t)n_rows);
+                uint4 * o = v.data() + at;
+                const uint32_t where = ((uint32_t)g << 6) | (pxmask << 9);
+                int mo = ay0 * it.mask_stride + ax, so = ay0 * it.src_stride + ax;
+                for(int y = y1; y <= y2; y++, mo += it.mask_stride, so += it.src_stride)
+                    *o++ = make_uint4(id, (uint32_t)y | where, (uint32_t)mo, (uint32_t)so);
+                p.stats.px_chunks += (int64_t)popcount8(pxmask) * n_rows;
             }
         }
         flush();
@@ -835,7 +841,7 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     int rc;
     bool used_list = false;
     if(plan) {  // describe, do not draw
-        ListPlan p;
+        static thread_local ListPlan p;
         auto close_segment = [&](bool all_tiles) {
             if(lb.items.empty() && !all_tiles) return;
             build_plan(lb, all_tiles, p);
