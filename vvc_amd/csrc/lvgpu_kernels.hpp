@@ -219,6 +219,21 @@ __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_
 {
     return blend_group_s<SRC, OM_RUNTIME, true>(a, d, sw, mk, scan0, fnb);
 }
+// The full-frame kernels decide per pixel, except for the one case their traffic is dominated by: an image with
+// per-pixel alpha (or a masked fill / map) at full opacity under the normal blend function -- nothing but
+// lv_color_mix with the pixel's own alpha.  The flag is uniform over the launch.  The kernels stay HBM-bound on the
+// whole chip either way; on a fraction of the CUs (32 of 256: +25 %) the shorter instruction stream is what counts.
+template <class A>
+__device__ __forceinline__ bool is_mix_only(const A & a)
+{
+    return a.blend_fn == BF_NORMAL && a.opa_mode == OM_MASK;
+}
+template <int SRC, class A>
+__device__ __forceinline__ uint4 blend_group_u(const A & a, bool mix_only, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0,
+                                               uint32_t fnb)
+{
+    return mix_only ? blend_group_mix<SRC, OM_MASK>(a, d, sw, mk) : blend_group<SRC>(a, d, sw, mk, scan0, fnb);
+}
 
 // The panel image is written once and never read back by these kernels: a non-temporal store keeps it from
 // displacing the draw-buffer lines that are still being read-modified-written in L2 (measured +2 % on the fused path).
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
     const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+    const bool mix_only = is_mix_only(a);
     const uint32_t g0 = c * LIN_CHUNK + threadIdx.x;
 
     uint4 d[LIN_UNROLL];
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
         if(g < gpf) {
             uint4 r = d[u];
             if(BLEND) {
-                r = blend_group<SRC>(a, d[u], sw[u], mk[u], g * 8, fnb);
+                r = blend_group_u<SRC>(a, mix_only, d[u], sw[u], mk[u], g * 8, fnb);
                 *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.out) {
@@ -366,12 +382,13 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
                 if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
             }
         }
+        const bool mix_only = is_mix_only(a);
 #pragma unroll
         for(int i = 0; i < 8; i++) {
             r[i] = d[i];
             if(BLEND) {
                 const size_t p = (size_t)(y0 + i) * W + x0;
-                r[i] = blend_group<SRC>(a, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                r[i] = blend_group_u<SRC>(a, mix_only, d[i], sw[i], mk[i], (uint32_t)p, fnb);
                 *reinterpret_cast<uint4 *>(dst + p) = r[i];
             }
             if(a.swap_out) r[i] = swap_group(r[i]);
@@ -442,6 +459,7 @@ __global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
     const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+    const bool mix_only = is_mix_only(a);
     uint16_t * out = a.out + (long long)f * a.out_fs;
 
     uint4 d[8];
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32
                 r[i] = d[i];
                 if(BLEND) {
                     const size_t p = (size_t)(y0 + i) * W + x0;
-                    r[i] = blend_group<SRC>(a, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    r[i] = blend_group_u<SRC>(a, mix_only, d[i], sw[i], mk[i], (uint32_t)p, fnb);
                     *reinterpret_cast<uint4 *>(dst + p) = r[i];
                 }
                 if(a.swap_out) r[i] = swap_group(r[i]);
