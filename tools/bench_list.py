@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--items", type=int, default=300)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--only-list", action="store_true")
+    ap.add_argument("--rot", type=int, default=1, help="flush rotation (LV_DISP_ROT_*: 0, 1 = 90, 2 = 180, 3 = 270 degrees)")
     ap.add_argument("--scene", default=None, help="a golden display list recorded from LVGL (tests/golden/scene*.npz)")
     a = ap.parse_args()
     W, H, N = 480, 320, a.frames
@@ -80,10 +81,10 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fl = _lib.FlushBatch()
     fl.inp, fl.in_frame_stride, fl.out, fl.out_frame_stride = buf.data_ptr(), H * W, out.data_ptr(), H * W
-    fl.width, fl.height, fl.rotation, fl.swap_bytes, fl.n_frames = W, H, 1, 0, N
+    fl.width, fl.height, fl.rotation, fl.swap_bytes, fl.n_frames = W, H, a.rot, 0, N
 
     def run_list():
-        _lib.check(L.lvgpu_blend_list_flush_batch(C.byref(geom), arr, len(dscs), out.data_ptr(), H * W, 1, 0, st))
+        _lib.check(L.lvgpu_blend_list_flush_batch(C.byref(geom), arr, len(dscs), out.data_ptr(), H * W, a.rot, 0, st))
 
     def run_seq():
         for i in range(len(dscs)):
@@ -91,7 +92,7 @@ def main():
         _lib.check(L.lvgpu_flush_rotate_batch(C.byref(fl), st))
 
     handle = C.c_void_p()
-    _lib.check(L.lvgpu_list_create(C.byref(geom), arr, len(dscs), 1, 1, 0, C.byref(handle)))
+    _lib.check(L.lvgpu_list_create(C.byref(geom), arr, len(dscs), 1, a.rot, 0, C.byref(handle)))
 
     def run_compiled():
         _lib.check(L.lvgpu_list_replay(handle, None, 0, out.data_ptr(), H * W, st))
