@@ -224,7 +224,7 @@ __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_
 // lv_color_mix with the pixel's own alpha.  The flag is uniform over the launch.  The kernels stay HBM-bound on the
 // whole chip either way; on a fraction of the CUs (32 of 256: +25 %) the shorter instruction stream is what counts.
 template <class A>
-__device__ __forceinline__ bool is_mix_only(const A & a)
+__host__ __device__ __forceinline__ bool is_mix_only(const A & a)
 {
     return a.blend_fn == BF_NORMAL && a.opa_mode == OM_MASK;
 }
