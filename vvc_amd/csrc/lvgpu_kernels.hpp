@@ -219,20 +219,30 @@ __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_
 {
     return blend_group_s<SRC, OM_RUNTIME, true>(a, d, sw, mk, scan0, fnb);
 }
-// The full-frame kernels decide per pixel, except for the one case their traffic is dominated by: an image with
-// per-pixel alpha (or a masked fill / map) at full opacity under the normal blend function -- nothing but
-// lv_color_mix with the pixel's own alpha.  The flag is uniform over the launch.  The kernels stay HBM-bound on the
-// whole chip either way; on a fraction of the CUs (32 of 256: +25 %) the shorter instruction stream is what counts.
-template <class A>
-__host__ __device__ __forceinline__ bool is_mix_only(const A & a)
+// The full-frame kernels decide per pixel, except for the two cases whose cost is all memory traffic; the choice is
+// uniform over the launch:
+//   FAST_MIX     an image with per-pixel alpha (or a masked fill / map) at full opacity under the normal blend function:
+//                nothing but lv_color_mix with the pixel's own alpha.  The kernels stay HBM-bound on the whole chip
+//                either way; on a fraction of the CUs (32 of 256: +25 %) the shorter instruction stream is what counts.
+//   FAST_OPAQUE  fill_normal / map_normal without mask at opa >= LV_OPA_MAX (lv_draw_sw_blend.c:254-259, :655-660:
+//                lv_color_fill / lv_memcpy per row): the destination is only written, so it is not loaded either.
+enum FastPath : int { FAST_NONE = 0, FAST_MIX = 1, FAST_OPAQUE = 2 };
+template <int SRC, class A>
+__host__ __device__ __forceinline__ int fast_path(const A & a)
 {
-    return a.blend_fn == BF_NORMAL && a.opa_mode == OM_MASK;
+    constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
+    if(SRC == SRC_COPY || a.blend_fn != BF_NORMAL) return FAST_NONE;
+    if(a.opa_mode == OM_MASK) return FAST_MIX;
+    if(a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha) return FAST_OPAQUE;
+    return FAST_NONE;
 }
 template <int SRC, class A>
-__device__ __forceinline__ uint4 blend_group_u(const A & a, bool mix_only, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0,
+__device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0,
                                                uint32_t fnb)
 {
-    return mix_only ? blend_group_mix<SRC, OM_MASK>(a, d, sw, mk) : blend_group<SRC>(a, d, sw, mk, scan0, fnb);
+    if(fast == FAST_MIX) return blend_group_mix<SRC, OM_MASK>(a, d, sw, mk);
+    if(fast == FAST_OPAQUE) return blend_group_s<SRC, OM_OPAQUE, false>(a, d, sw, mk, scan0, fnb);
+    return blend_group<SRC>(a, d, sw, mk, scan0, fnb);
 }
 
 // The panel image is written once and never read back by these kernels: a non-temporal store keeps it from
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
     const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-    const bool mix_only = is_mix_only(a);
+    const int fast = fast_path<SRC>(a);
     const uint32_t g0 = c * LIN_CHUNK + threadIdx.x;
 
     uint4 d[LIN_UNROLL];
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
         const uint32_t g = g0 + u * 256;
         mk[u] = make_uint2(0, 0);
         if(g < gpf) {
-            d[u] = *reinterpret_cast<const uint4 *>(dst + (size_t)g * 8);
+            d[u] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + (size_t)g * 8);
             if(BLEND) {
                 if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)g * 8, sw[u]);
                 if(mask) mk[u] = *reinterpret_cast<const uint2 *>(mask + (size_t)g * 8);
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
         if(g < gpf) {
             uint4 r = d[u];
             if(BLEND) {
-                r = blend_group_u<SRC>(a, mix_only, d[u], sw[u], mk[u], g * 8, fnb);
+                r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], g * 8, fnb);
                 *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.out) {
@@ -369,26 +379,26 @@ __global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_
         const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
         const long long src_px0 = (long long)f * a.src_fs;
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+        const int fast = fast_path<SRC>(a);
         uint4 d[8];
         uint2 mk[8];
         uint32_t sw[8][SrcWords<SRC>::N];
 #pragma unroll
         for(int i = 0; i < 8; i++) {
             const size_t p = (size_t)(y0 + i) * W + x0;
-            d[i] = *reinterpret_cast<const uint4 *>(dst + p);
+            d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
             mk[i] = make_uint2(0, 0);
             if(BLEND) {
                 if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
                 if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
             }
         }
-        const bool mix_only = is_mix_only(a);
 #pragma unroll
         for(int i = 0; i < 8; i++) {
             r[i] = d[i];
             if(BLEND) {
                 const size_t p = (size_t)(y0 + i) * W + x0;
-                r[i] = blend_group_u<SRC>(a, mix_only, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
                 *reinterpret_cast<uint4 *>(dst + p) = r[i];
             }
             if(a.swap_out) r[i] = swap_group(r[i]);
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
     const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-    const bool mix_only = is_mix_only(a);
+    const int fast = fast_path<SRC>(a);
     uint16_t * out = a.out + (long long)f * a.out_fs;
 
     uint4 d[8];
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32
 #pragma unroll
         for(int i = 0; i < 8; i++) {
             const size_t p = (size_t)(y0 + i) * W + x0;
-            d[i] = *reinterpret_cast<const uint4 *>(dst + p);
+            d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
             mk[i] = make_uint2(0, 0);
             if(BLEND) {
                 if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32
                 r[i] = d[i];
                 if(BLEND) {
                     const size_t p = (size_t)(y0 + i) * W + x0;
-                    r[i] = blend_group_u<SRC>(a, mix_only, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
                     *reinterpret_cast<uint4 *>(dst + p) = r[i];
                 }
                 if(a.swap_out) r[i] = swap_group(r[i]);
