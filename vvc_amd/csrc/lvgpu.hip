@@ -205,11 +205,11 @@ int dispatch_src(int fmt, Args &&... args)
 // memory system sees at once.  With the whole device streaming, fewer residents reach a higher HBM rate for the
 // plain-mix case (few instructions per byte): the linear kernel 70.3 -> 73.7 % of peak at three workgroups per CU
 // instead of eight (a masked fill, with less to load per lane, likes four), the fused tile kernel 67.4 -> 69.3 % at two
-// instead of three.  Residency is capped at launch by
+// instead of three, the rotation alone 72.7 -> 73.6 % (each value sits in the middle of a measured plateau).  Residency is capped at launch by
 // asking for dynamic LDS the kernels never touch (160 KB per CU).  On a stream confined to some of the CUs (a CU mask)
 // the same cap costs 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied
 // only to plain-mix launches on streams that own the whole device.
-constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024;
+constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 16 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     static thread_local int dev_cached = -1, dev_cus = 0;
@@ -237,7 +237,10 @@ struct LaunchLinear {
         const uint32_t cpf = (gpf + LIN_CHUNK - 1) / LIN_CHUNK;
         const uint64_t blocks = (uint64_t)cpf * a.n_frames;
         if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const uint32_t pad = fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS) : 0;
+        const int fast = fast_path<SRC>(a);
+        uint32_t pad = 0;
+        if(fast == FAST_MIX) pad = residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS);
+        else if(fast == FAST_OPAQUE && SRC != SRC_FILL) pad = residency_pad(st, LIN_PAD_LDS_FILL);  // a copy: 74.6 -> 76.5 %
         hipLaunchKernelGGL(k_blend_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
@@ -252,7 +255,8 @@ struct LaunchTile {
         const uint32_t tpf = tiles_x * tiles_y;
         const uint64_t n_tiles = (uint64_t)tpf * a.n_frames;
         if(n_tiles > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const uint32_t pad = fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, TILE_PAD_LDS) : 0;
+        const uint32_t pad = SRC == SRC_COPY ? residency_pad(st, TILE_PAD_LDS_COPY)
+                                             : (fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, TILE_PAD_LDS) : 0);
         hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), pad, st, a, W, H, tiles_x, tiles_y,
                            tpf, (uint32_t)n_tiles);
         HIP_TRY(hipGetLastError());
