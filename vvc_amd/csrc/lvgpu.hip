@@ -204,12 +204,13 @@ int dispatch_src(int fmt, Args &&... args)
 // How many workgroups of the full-frame blend kernels share a CU decides how many independent address streams the
 // memory system sees at once.  With the whole device streaming, fewer residents reach a higher HBM rate for the
 // plain-mix case (few instructions per byte): the linear kernel 70.3 -> 73.7 % of peak at three workgroups per CU
-// instead of eight (a masked fill, with less to load per lane, likes four), the fused tile kernel 67.4 -> 69.3 % at two
-// instead of three, the rotation alone 72.7 -> 73.6 % (each value sits in the middle of a measured plateau).  Residency is capped at launch by
+// instead of eight (a masked fill, with less to load per lane, likes four), the fused tile kernel 66.4 -> 70.0 %, the
+// rotation alone 70.4 -> 74.5 % (each value sits on a measured plateau; the RGB565 + A8 source and 4K canvases fall
+// off right above the tile kernel's value).  Residency is capped at launch by
 // asking for dynamic LDS the kernels never touch (160 KB per CU).  On a stream confined to some of the CUs (a CU mask)
 // the same cap costs 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied
 // only to plain-mix launches on streams that own the whole device.
-constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 16 * 1024;
+constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     static thread_local int dev_cached = -1, dev_cus = 0;
@@ -257,8 +258,8 @@ struct LaunchTile {
         if(n_tiles > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
         const uint32_t pad = SRC == SRC_COPY ? residency_pad(st, TILE_PAD_LDS_COPY)
                                              : (fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, TILE_PAD_LDS) : 0);
-        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + 3) / 4)), dim3(256), pad, st, a, W, H, tiles_x, tiles_y,
-                           tpf, (uint32_t)n_tiles);
+        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + TILE_WPB - 1) / TILE_WPB)), dim3(64 * TILE_WPB), pad, st, a, W, H,
+                           tiles_x, tiles_y, tpf, (uint32_t)n_tiles);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }

@@ -342,15 +342,18 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
 // of output row (8k + l>>3) at 16-B chunk (l&7), so 8 consecutive lanes store 128 contiguous bytes.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TILE = 64;
+// Wavefronts (= tiles) per workgroup of k_tile.  Two rather than four: the launcher caps how many workgroups share a
+// CU, and small workgroups let it do so in steps of two waves (measured: +1 % fused, +1 % rotation alone).
+constexpr int TILE_WPB = 2;
 
 template <int SRC>
-__global__ __launch_bounds__(256) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpf,
+__global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpf,
                                               uint32_t n_tiles)
 {
-    __shared__ uint4 lds[4][512];
+    __shared__ uint4 lds[TILE_WPB][512];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
+    const uint32_t wt = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * TILE_WPB + wave);
     const bool live = wt < n_tiles;
     const uint32_t f = live ? wt / tpf : 0;
     const uint32_t t = live ? wt - f * tpf : 0;
