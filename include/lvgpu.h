@@ -7,7 +7,9 @@
  * as void* (NULL = the default stream).  Every entry point returns LVGPU_OK (0) or a negative LVGPU_ERR_* code and
  * never throws; lvgpu_last_error() gives the text of the last failure on the calling thread.  Calls are
  * asynchronous with respect to the host unless stated otherwise.  Entry points may be called from several host
- * threads as long as each thread uses its own device/stream.
+ * threads as long as each thread uses its own device/stream.  The full-frame kernels look at the stream's CU mask
+ * (hipExtStreamGetCUMask): on a stream that owns the whole device they cap how many workgroups share a CU, which
+ * raises the HBM rate; a stream confined to some CUs keeps the default.  Results do not depend on it.
  *
  * Pixel vocabulary (libraries/lvgl/src/misc/lv_color.h:208-222): a pixel is lv_color16_t, 2 bytes.
  *   color_16_swap = 1 : LV_COLOR_16_SWAP 1, memory bytes {RRRRRGGG, GGGBBBBB} (big-endian RGB565 = panel wire order)
