@@ -211,7 +211,7 @@ int dispatch_src(int fmt, Args &&... args)
 // the same cap costs 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied
 // only to plain-mix launches on streams that own the whole device.
 constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
-                   ROWS_PAD_LDS = 24 * 1024;
+                   ROWS_PAD_LDS = 24 * 1024, ARGB_PAD_LDS = 16 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     static thread_local int dev_cached = -1, dev_cus = 0;
@@ -284,7 +284,8 @@ struct LaunchArgbLinear {
         const uint32_t cpf = (gpf + 256 * ARGB_UNROLL - 1) / (256 * ARGB_UNROLL);
         const uint64_t blocks = (uint64_t)cpf * a.n_frames;
         if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), 0, st, a, gpf, cpf);
+        const uint32_t pad = a.has_mask ? residency_pad(st, ARGB_PAD_LDS) : 0;  // masked fill 50.3 -> 54.2 % of peak
+        hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
