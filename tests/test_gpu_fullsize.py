@@ -164,3 +164,39 @@ def test_two_host_threads_on_their_own_streams(gpu, oracle):
     for t in ts:
         t.join()
     assert results == {0: True, 1: True}, results
+
+
+def test_results_do_not_depend_on_the_streams_cu_mask(gpu):
+    """On a stream that owns the whole device the full-frame kernels cap how many workgroups share a CU; a stream
+    confined to 32 CUs keeps the default.  Both give the same bytes: fused blend + flush, blend alone, rotation alone,
+    a masked fill, an opaque map."""
+    n = 256
+    area = (0, 0, W - 1, H - 1)
+    src = gpu.synth(gpu.SYNTH_ARGB_UI, 0x5EED0002, 0, (n, H, W))
+    s565 = gpu.synth(gpu.SYNTH_U16, 0x5EED0004, 0, (n, H, W))
+    mask = gpu.synth(gpu.SYNTH_MASK_UI, 0x5EED0003, 0, (n, H, W))
+    dscs = [gpu.BlendDsc(area, src_buf=src, src_format=gpu.SRC_ARGB8888),
+            gpu.BlendDsc(area, color=0x1234, mask_buf=mask, opa=255),
+            gpu.BlendDsc(area, src_buf=s565, opa=255),
+            gpu.BlendDsc(area, src_buf=s565, mask_buf=mask, opa=180)]
+    ms = gpu.MaskedStream(range(32))
+    try:
+        torch.cuda.synchronize()
+        for dsc in dscs:
+            res = []
+            for stream in (None, ms.handle):
+                d = gpu.synth(gpu.SYNTH_U16, 0x5EED0001, 0, (n, H, W))
+                torch.cuda.synchronize()
+                out = gpu.blend_flush(gpu.DrawCtx(d), dsc, gpu.LV_DISP_ROT_90, stream=stream)
+                d2 = gpu.synth(gpu.SYNTH_U16, 0x5EED0001, 0, (n, H, W))
+                torch.cuda.synchronize()
+                gpu.lv_draw_sw_blend(gpu.DrawCtx(d2), dsc, stream=stream)
+                r = gpu.flush_rotate(d2, gpu.LV_DISP_ROT_270, stream=stream)
+                ms.synchronize()
+                torch.cuda.synchronize()
+                res.append((d, out, d2, r))
+            for a, b in zip(res[0], res[1]):
+                assert torch.equal(a, b)
+            assert torch.equal(res[0][0], res[0][2])
+    finally:
+        ms.close()
