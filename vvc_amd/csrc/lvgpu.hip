@@ -203,13 +203,13 @@ int dispatch_src(int fmt, Args &&... args)
 
 // How many workgroups of the full-frame blend kernels share a CU decides how many independent address streams the
 // memory system sees at once.  With the whole device streaming, fewer residents reach a higher HBM rate for the
-// plain-mix case (few instructions per byte): the linear kernel 70.3 -> 73.7 % of peak at three workgroups per CU
-// instead of eight (a masked fill, with less to load per lane, likes four), the fused tile kernel 66.4 -> 70.0 %, the
-// rotation alone 70.4 -> 74.5 % (each value sits on a measured plateau; the RGB565 + A8 source and 4K canvases fall
-// off right above the tile kernel's value).  Residency is capped at launch by
-// asking for dynamic LDS the kernels never touch (160 KB per CU).  On a stream confined to some of the CUs (a CU mask)
-// the same cap costs 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied
-// only to plain-mix launches on streams that own the whole device.
+// plain-mix case (few instructions per byte): the linear kernel 70.3 -> 73.7 % of peak, the fused tile kernel
+// 66.4 -> 70.0 %, the rotation alone 70.4 -> 74.5 %.  Residency is capped at launch by asking for dynamic LDS the
+// kernels never touch; the values below sit on measured plateaus of the rate against the requested size (a masked
+// fill, with less to load per lane, likes more residents than an image; the RGB565 + A8 source and 4K canvases fall
+// off right above the tile kernel's value).  On a stream confined to some of the CUs (a CU mask) the same cap costs
+// 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied only to the
+// launches named at its uses, on streams that own the whole device.
 constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
                    ROWS_PAD_LDS = 24 * 1024, ARGB_PAD_LDS = 16 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
