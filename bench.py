@@ -1,53 +1,130 @@
 #!/usr/bin/env python3
 """Benchmark of the batched LVGL pixel path on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic frames, device-resident:
-    workload "blend_flush" (default): an ARGB8888 image alpha-blended over every RGB565 480x320 draw buffer
-        (lv_draw_sw_blend, map_normal with per-pixel alpha) fused with the 90-degree flush rotation into
-        the 320x480 panel image -- 4 B + 2 B read, 2 B + 2 B written per pixel = 10 algorithmic bytes/px.
-    workload "blend": the blend alone (8 bytes/px).   workload "rotate": the flush rotation alone (4 bytes/px).
-    workload "scene": a widget scene recorded from the real LVGL (tests/golden/scene2_*.npz, 1649 blend descriptors)
-        replayed over every frame as ONE display list with the fused flush; bytes/px counts what must move (draw
-        buffer and panel image written once each, 4 bytes/px) -- this kernel is bound by VALU issue, not by HBM.
-Frames are sharded over ranks (one process per GPU), there is no data-path collective; torch.distributed is used
-only for the barrier and the max-over-ranks time.
+One "step" = one pass of the hot path over one batch of synthetic frames, device-resident.  Workloads:
+    blend_flush (default)  an ARGB8888 image alpha-blended over every RGB565 480x320 draw buffer (lv_draw_sw_blend,
+                           map_normal with per-pixel alpha) fused with the 90-degree flush rotation into the 320x480
+                           panel image: 4 B + 2 B read, 2 B + 2 B written per pixel = 10 algorithmic bytes/px.
+                           With --swap 0 the buffers are LV_COLOR_16_SWAP 0 and the flush byte-swaps into wire order.
+    blend / rotate         the blend alone (8 B/px) / the flush rotation alone (4 B/px)
+    blend_rgb565a8, blend_flush_rgb565a8   the same with a colour plane + A8 plane source (7 / 9 B/px)
+    blend_flush_4k         blend_flush on 3840x2160 canvases (64 frames per GPU by default)
+    clipped_small, clipped_large   lv_draw_sw_blend of a per-frame RGB565 image + A8 mask over a clipped,
+                           misaligned area (201x101 at an odd x / 468x296 at x = 3) of 480x320 buffers; pixels
+                           counted are the area's (7 B/px)
+    fill_translucent       fill_normal without mask at opa 128 (premultiplied formula + scan-order pre-pass), 4 B/px
+    fill_opaque / map_opaque   lv_color_fill per row (2 B/px, write only) / row copy (4 B/px)
+    fill_masked            fill_normal with an A8 mask at opa 255 (5 B/px)
+    fill_masked_argb       the same into a 3-byte ARGB8565 draw buffer (screen_transp): 3 R + 3 W + 1 R = 7 B/px
+    scene                  a widget scene recorded from the real LVGL (tests/golden/scene2_*.npz, 1649 blend
+                           descriptors) replayed over every frame as ONE display list with the fused flush; bytes/px
+                           counts what must move (draw buffer and panel image written once each, 4 B/px) -- this
+                           kernel is bound by VALU issue, not by HBM.
+Frames are sharded over ranks (one process per GPU), there is no data-path collective; torch.distributed is used only
+for the barrier and the max-over-ranks time.
+
+`--gpus N` with N > 1 and no torchrun environment: this process starts N ranks as a child
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) before it touches any GPU, relays the child's
+output and exit code.  With more than one rank the default batch is 65 536 frames in total (sharded per frame,
+"strong" scaling); `--frames-per-gpu` fixes the per-GPU batch instead ("weak").
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-from vvc_amd import lvgpu, sharding  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 SEED_DST, SEED_SRC, SEED_MASK = 0x5EED0001, 0x5EED0002, 0x5EED0003
-BYTES_PER_PX = {"blend_flush": 10, "blend": 8, "rotate": 4, "blend_rgb565a8": 7, "blend_flush_rgb565a8": 9, "scene": 4}
+MULTI_GPU_TOTAL_FRAMES = 65536  # the batch that is sharded over 2/4/8 GPUs
+# workload -> (algorithmic bytes per pixel, default logical width, height, default frames per GPU on one GPU)
+WORKLOADS = {
+    "blend_flush": (10, 480, 320, 4096), "blend": (8, 480, 320, 4096), "rotate": (4, 480, 320, 4096),
+    "blend_rgb565a8": (7, 480, 320, 4096), "blend_flush_rgb565a8": (9, 480, 320, 4096), "scene": (4, 480, 320, 4096),
+    "blend_flush_4k": (10, 3840, 2160, 64),
+    "clipped_small": (7, 480, 320, 4096), "clipped_large": (7, 480, 320, 4096),
+    "fill_translucent": (4, 480, 320, 4096), "fill_opaque": (2, 480, 320, 4096), "map_opaque": (4, 480, 320, 4096),
+    "fill_masked": (5, 480, 320, 4096), "fill_masked_argb": (7, 480, 320, 4096),
+}
+CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300)}
+KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_kernels.hpp", "lvgpu_list.hpp", "lvgpu_px.hpp")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="blend_flush", choices=sorted(BYTES_PER_PX))
-    ap.add_argument("--frames-per-gpu", type=int, default=4096)
-    ap.add_argument("--width", type=int, default=480, help="logical LVGL width (panel is rotated)")
-    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--workload", default="blend_flush", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=0,
+                    help="frames each GPU processes (default: 4096 on one GPU -- 64 for blend_flush_4k --, "
+                         "65536 / N on N > 1 GPUs)")
+    ap.add_argument("--width", type=int, default=0, help="logical LVGL width (panel is rotated)")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--rotation", type=int, default=1)
     ap.add_argument("--swap", type=int, default=1, help="LV_COLOR_16_SWAP of the buffers (firmware: 1)")
     ap.add_argument("--mask", default="ui", choices=["ui", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eighth", action="store_true", help="skip the 32-CU (1/8 of the CUs) measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def frames_for(frames_per_gpu, world, one_gpu_default):
+    """(frames per GPU, scaling): an explicit per-GPU batch is "weak" scaling; otherwise one GPU runs the workload's
+    single-GPU batch and N > 1 GPUs share the 65 536-frame batch (scaled down for workloads with a smaller default)."""
+    if frames_per_gpu > 0:
+        return frames_per_gpu, "weak"
+    if world > 1:
+        return max(1, (MULTI_GPU_TOTAL_FRAMES * one_gpu_default // 4096) // world), "strong"
+    return one_gpu_default, "weak"
+
+
+def kernel_sources_sha():
+    """Identifies the kernel sources a profile was taken with (profiles/traffic.json carries the same digest)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "vvc_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a torchrun environment: start the ranks as a child process.  Nothing here may touch the GPU: no
+# torch.cuda call that initialises it, no liblvgpu call (the children own the devices).
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_command(n, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Runs `bench.py argv` on n ranks of this node and returns the child's exit code."""
+    if os.environ.get("LVGPU_BENCH_ONE_DEVICE") != "1":
+        import torch  # counting devices does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d GPU(s) visible" % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(spawn_command(n, argv, free_port()), env=env).returncode
 
 
 def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
@@ -61,24 +138,31 @@ def cpu_baseline(args, W, H, d0_first_frames_after_one_step, out_first):
     px = W * H
     n = 256
     kind = O.SYNTH_ARGB_UI if args.mask == "ui" else O.SYNTH_ARGB_UNI
+    swap_bytes = 0 if args.swap else 1
     dst = O.synth(O.SYNTH_U16, SEED_DST, 0, n * px)
     src = O.synth(kind, SEED_SRC, 0, n * px)
     out = np.empty(n * px, np.uint16)
     want_out = args.workload != "blend"
+
+    def run(d, s, o, k):
+        O.argb_blend_flush_batch(d, s, o, W, H, k, args.rotation, args.swap, threads)
+        if o is not None and swap_bytes:  # LV_COLOR_16_SWAP 0 buffers reach the panel byte-swapped (src/display.h:26-30)
+            o.byteswap(inplace=True)
+
     # parity of the first frames (one step applied to fresh inputs)
     chk = dst[: 4 * px].copy()
     chk_out = np.empty(4 * px, np.uint16)
-    O.argb_blend_flush_batch(chk, src, chk_out, W, H, 4, args.rotation, args.swap, threads)
+    run(chk, src, chk_out, 4)
     ok = bool(np.array_equal(chk, d0_first_frames_after_one_step))
     if out_first is not None:
         ok = ok and bool(np.array_equal(chk_out, out_first))
     t0 = time.perf_counter()
-    O.argb_blend_flush_batch(dst, src, out if want_out else None, W, H, n, args.rotation, args.swap, threads)
+    run(dst, src, out if want_out else None, n)
     once = time.perf_counter() - t0
     reps = max(1, min(200, int(1.5 / max(once, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        O.argb_blend_flush_batch(dst, src, out if want_out else None, W, H, n, args.rotation, args.swap, threads)
+        run(dst, src, out if want_out else None, n)
     dt = time.perf_counter() - t0
     ref_lvgl = None
     try:  # the reference's own blend (LVGL compiled from its sources into oracle/_ref), one thread, blend part only
@@ -112,7 +196,6 @@ def cpu_baseline_scene(args, W, H, rec, d_first, o_first):
     """The scene workload on the host: the oracle replays the recorded descriptors frame by frame (OpenMP over frames)
     and applies the restated flush rotation; where the real LVGL (oracle/_ref) is present it also renders the same
     widget scene itself, rasterisers included, on one thread."""
-    import ctypes as C
     import numpy as np
     from oracle import lvref_py as O
     O.build()
@@ -159,10 +242,11 @@ def cpu_baseline_scene(args, W, H, rec, d_first, o_first):
     }
 
 
-def eighth_gpu(args, step_on, n_px, bpp, copy_on=None):
+def eighth_gpu(lvgpu, step_on, n_px, bpp, copy_on=None):
     """The same launch restricted to 32 of the 256 CUs (hipExtStreamCreateWithCUMask), i.e. 1/8 of the GPU's compute.
     The runtime deals CU-mask bits round-robin over the XCDs and rejects a mask that leaves an XCD empty, so the
-    32 CUs are 4 per XCD; the memory system behind them is the whole device's."""
+    32 CUs are 4 per XCD; the memory system behind them is the whole device's: this is NOT a memory partition, and
+    the figure to read is frac_of_measured_copy (against what the same 32 CUs reach on a plain copy)."""
     try:
         ms = lvgpu.MaskedStream(range(32))
     except lvgpu.LvgpuError as e:
@@ -197,8 +281,33 @@ def eighth_gpu(args, step_on, n_px, bpp, copy_on=None):
     return res
 
 
-def main():
-    args = parse()
+def profiled_traffic(workload, n, W, H, swap):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), only when they were
+    taken for exactly this launch shape with exactly these kernel sources; otherwise (None, why)."""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tj) as f:
+            t = json.load(f)
+    except Exception:
+        return None, "no profiles/traffic.json"
+    e = t.get("workloads", {}).get(workload if swap else workload + "_swap0")
+    if not isinstance(e, dict):
+        return None, "workload not profiled"
+    if [n, W, H] != e.get("shape"):
+        return None, "profiled for another shape"
+    if t.get("kernel_sources_sha") != kernel_sources_sha():
+        return None, "kernel sources changed since the profile in %s" % t.get("source", "profiles/")
+    return e.get("hbm_bytes_per_launch"), t.get("source", "profiles/")
+
+
+def main(argv=None):
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+
+    import torch
+    from vvc_amd import lvgpu, sharding
+
     # LVGPU_BENCH_BACKEND=gloo + LVGPU_BENCH_ONE_DEVICE=1 rehearse the multi-rank code path on a single GPU
     # (all ranks share device 0; the numbers are then meaningless, the control flow is what is exercised).
     backend = os.environ.get("LVGPU_BENCH_BACKEND", "nccl")
@@ -206,37 +315,77 @@ def main():
     if one_dev:
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local_rank, dist = sharding.init(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world > 1 and not one_dev and torch.cuda.device_count() < env_world:
+        sys.exit("bench.py: %d ranks but %d GPU(s) visible" % (env_world, torch.cuda.device_count()))
+    rank, world, local_rank, dist = sharding.init(backend if env_world > 1 else None)
+    if args.gpus > 1 and args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.cuda.current_device()
     lvgpu.init(dev)
 
-    W, H, n = args.width, args.height, args.frames_per_gpu
+    wl = args.workload
+    bpp, W0, H0, n0 = WORKLOADS[wl]
+    W, H = args.width or W0, args.height or H0
+    n, scaling = frames_for(args.frames_per_gpu, world, n0)
     px = W * H
     lo, hi = sharding.frame_range(rank, world, n * world)  # this rank's global frame indices
     assert hi - lo == n
     first = lo * px  # global element index of this shard: inputs depend only on the global frame index
-    kind = lvgpu.SYNTH_ARGB_UI if args.mask == "ui" else lvgpu.SYNTH_ARGB_UNI
-    dst = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
-    src = lvgpu.synth(kind, SEED_SRC, first, (n, H, W))
     rot = args.rotation
-    out_shape = (n, W, H) if rot in (1, 3) else (n, H, W)
-    out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
-    ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap)
-    area = (0, 0, W - 1, H - 1)
-    dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
-    if args.workload.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
-        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
-        a8 = lvgpu.synth(lvgpu.SYNTH_MASK_UI if args.mask == "ui" else lvgpu.SYNTH_MASK_UNI, SEED_MASK, first, (n, H, W))
-        dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
     swap_bytes = 0 if args.swap else 1
-    blist, rec = None, None
-    if args.workload == "scene":
+    area = (0, 0, W - 1, H - 1)
+    mask_kind = lvgpu.SYNTH_MASK_UI if args.mask == "ui" else lvgpu.SYNTH_MASK_UNI
+    argb_kind = lvgpu.SYNTH_ARGB_UI if args.mask == "ui" else lvgpu.SYNTH_ARGB_UNI
+    px_per_frame = px  # pixels one frame contributes to the metric
+    keep = []          # tensors the descriptors point into
+
+    out = None
+    wants_out = wl in ("blend_flush", "blend_flush_rgb565a8", "blend_flush_4k", "rotate", "scene")
+    if wl == "fill_masked_argb":
+        dst = lvgpu.synth(lvgpu.SYNTH_MASK_UNI, SEED_DST, first * 3, (n, H, W, 3))
+        ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap, screen_transp=1)
+    else:
+        dst = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
+        ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap)
+    if wants_out:
+        out_shape = (n, W, H) if rot in (1, 3) else (n, H, W)
+        out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
+
+    dsc, blist, rec = None, None, None
+    if wl in ("blend_flush", "blend", "blend_flush_4k"):
+        src = lvgpu.synth(argb_kind, SEED_SRC, first, (n, H, W))
+        dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
+    elif wl.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
+        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
+        a8 = lvgpu.synth(mask_kind, SEED_MASK, first, (n, H, W))
+        dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
+    elif wl in CLIPPED_AREAS:
+        ba = CLIPPED_AREAS[wl]
+        bw, bh = ba[2] - ba[0] + 1, ba[3] - ba[1] + 1
+        px_per_frame = bw * bh
+        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, lo * px_per_frame, (n, bh, bw))
+        a8 = lvgpu.synth(mask_kind, SEED_MASK, lo * px_per_frame, (n, bh, bw))
+        dsc = lvgpu.BlendDsc(ba, src_buf=src16, mask_buf=a8, opa=255)
+    elif wl == "fill_translucent":
+        # colour 0x1234 at opa 128: lv_color_mix and lv_color_mix_premult disagree on black, so the scan-order
+        # pre-pass (first non-black pixel of every frame) runs
+        dsc = lvgpu.BlendDsc(area, color=0x1234, opa=128)
+    elif wl == "fill_opaque":
+        dsc = lvgpu.BlendDsc(area, color=0x1234, opa=255)
+    elif wl == "map_opaque":
+        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
+        dsc = lvgpu.BlendDsc(area, src_buf=src16, opa=255)
+    elif wl in ("fill_masked", "fill_masked_argb"):
+        a8 = lvgpu.synth(mask_kind, SEED_MASK, first, (n, H, W))
+        dsc = lvgpu.BlendDsc(area, color=0x1234, mask_buf=a8, opa=255)
+    elif wl == "scene":
         assert (W, H) == (480, 320), "the recorded scenes are 480x320"
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from util import load_scene
         _fb, rec = load_scene(os.path.join(ROOT, "tests", "golden", "scene2_f0_swap%d.npz" % args.swap))
-        dscs, keep = [], []
+        dscs = []
         for r in rec:
             s16 = None if r["src"] is None else torch.from_numpy(r["src"].view("int16").copy()).cuda()
             m8 = None if r["mask"] is None else torch.from_numpy(r["mask"].copy()).cuda()
@@ -248,19 +397,22 @@ def main():
     def step(stream=None):
         if blist is not None:
             blist.replay(out=out, stream=stream)
-        elif args.workload.startswith("blend_flush"):
-            lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
-        elif args.workload.startswith("blend"):
-            lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
-        else:
+        elif wl == "rotate":
             lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out, stream=stream)
+        elif wants_out:
+            lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
+        else:
+            lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
 
     # first step on fresh inputs: keep the first frames for the CPU cross-check
     step()
     torch.cuda.synchronize()
     kernel = lvgpu.last_kernel()
-    d_first = dst[:4].cpu().numpy().view("uint16").reshape(-1).copy()
-    o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy() if ("flush" in args.workload or args.workload == "scene") else None
+    d_first = o_first = None
+    if wl in ("blend_flush", "blend", "scene"):
+        d_first = dst[:4].cpu().numpy().view("uint16").reshape(-1).copy()
+        if wants_out:
+            o_first = out[:4].cpu().numpy().view("uint16").reshape(-1).copy()
     for _ in range(max(0, args.warmup - 1)):
         step()
 
@@ -286,26 +438,43 @@ def main():
     torch.cuda.synchronize()
     per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(11))
     ev_median = per_step[5]
+    own_dt = dt
     dt, ev_ms, ev_median = sharding.max_over_ranks(dist, [dt, ev_ms, ev_median])
+    per_rank_dt = sharding.gather_floats(dist, own_dt)
 
     eighth = None
-    if rank == 0 and world == 1 and not args.no_eighth:
-        eighth = eighth_gpu(args, lambda st: step(st.value), px * n, BYTES_PER_PX[args.workload],
-                            copy_on=lambda st: lvgpu.flush_rotate(dst, 0, out=out.view(dst.shape), stream=st.value))
+    if rank == 0 and world == 1 and not args.no_eighth and wl in ("blend_flush", "blend", "rotate"):
+        cp_out = out.view(dst.shape) if out is not None else torch.empty_like(dst)
+        eighth = eighth_gpu(lvgpu, lambda st: step(st.value), px * n, bpp,
+                            copy_on=lambda st: lvgpu.flush_rotate(dst, 0, out=cp_out, stream=st.value))
         torch.cuda.synchronize()
 
     if rank == 0:
-        total_px = px * n * world * args.steps
-        bpp = BYTES_PER_PX[args.workload]
-        launch_s = ev_ms / 1e3 / args.steps  # one kernel launch per step: HIP events on the launch stream
-        achieved = bpp * px * n / launch_s / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj) and (n, W, H) == (4096, 480, 320):  # measured for exactly this launch shape
-            try:
-                traffic = json.load(open(tj)).get(args.workload)
-            except Exception:
-                traffic = None
+        total_px = px_per_frame * n * world * args.steps
+        launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream around the timed steps
+        achieved = bpp * px_per_frame * n / launch_s / 1e9
+        traffic, traffic_source = profiled_traffic(wl, n, W, H, args.swap)
+        if blist is not None:
+            desc = ("scene: %d LVGL blend descriptors (recorded widget scene) as one compiled display list + flush, "
+                    "LV_COLOR_16_SWAP %d, %dx%d logical, rotation %d, %d frames per GPU" % (blist.n, args.swap, W, H, rot * 90, n))
+        elif wl in CLIPPED_AREAS:
+            ba = CLIPPED_AREAS[wl]
+            desc = ("%s: lv_draw_sw_blend of a per-frame RGB565 image + A8 mask (%s) over the clipped area %s of %dx%d "
+                    "buffers, opa 255, LV_COLOR_16_SWAP %d, %d frames per GPU; pixels counted = the area's"
+                    % (wl, args.mask, list(ba), W, H, args.swap, n))
+        elif wl.startswith("fill") or wl == "map_opaque":
+            desc = ("%s: %s over whole %dx%d buffers, LV_COLOR_16_SWAP %d, %d frames per GPU"
+                    % (wl, {"fill_translucent": "fill_normal, no mask, opa 128 (premultiplied formula + scan-order pre-pass)",
+                            "fill_opaque": "fill_normal, no mask, opa 255 (lv_color_fill)",
+                            "map_opaque": "map_normal, no mask, opa 255 (row copy)",
+                            "fill_masked": "fill_normal with an A8 mask (%s), opa 255" % args.mask,
+                            "fill_masked_argb": "fill_argb with an A8 mask (%s), opa 255, into a 3-byte ARGB8565 draw "
+                                                "buffer (screen_transp)" % args.mask}[wl], W, H, args.swap, n))
+        else:
+            desc = ("%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d%s, %dx%d logical, "
+                    "rotation %d, %d frames per GPU"
+                    % (wl, args.mask, args.swap, " (flush byte-swaps into wire order)" if swap_bytes and wants_out else "",
+                       W, H, rot * 90, n))
         res = {
             "metric": "Mpixels/sec batched 320x480 RGB565 blend+rotate; % of HBM peak at 1/8 GPU",
             "value": round(total_px / dt / 1e6, 1),
@@ -315,31 +484,29 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic",
             "config": {
-                "workload": ("scene: %d LVGL blend descriptors (recorded widget scene) as one compiled display list + flush, "
-                             "LV_COLOR_16_SWAP %d, %dx%d logical, rotation %d, %d frames per GPU"
-                             % (blist.n, args.swap, W, H, rot * 90, n)) if blist is not None else
-                            "%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d, %dx%d logical, "
-                            "rotation %d, %d frames per GPU" % (args.workload, args.mask, args.swap, W, H, rot * 90, n),
+                "workload": desc,
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel, "algorithmic_bytes_per_px": bpp, "launch_ms": round(launch_s * 1e3, 4),
                 "launch_ms_median": round(ev_median, 4),
             },
             "pct_hbm_peak": round(100 * achieved / HBM_PEAK_GBS, 2),
         }
+        if world > 1:
+            res["per_rank_Mpx_s"] = [round(px_per_frame * n * args.steps / t / 1e6, 1) for t in per_rank_dt]
         if eighth is not None:
             res["eighth_gpu"] = eighth
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("blend_flush", "blend"):
+        if world == 1 and not args.no_cpu_baseline and wl in ("blend_flush", "blend"):
             res["cpu_baseline"] = cpu_baseline(args, W, H, d_first, o_first)
-        if world == 1 and not args.no_cpu_baseline and args.workload == "scene":
+        if world == 1 and not args.no_cpu_baseline and wl == "scene":
             res["cpu_baseline"] = cpu_baseline_scene(args, W, H, rec, d_first, o_first)
         print(json.dumps(res), flush=True)
     if dist is not None:

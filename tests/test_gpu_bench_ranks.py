@@ -1,0 +1,40 @@
+"""GPU: `bench.py --gpus 2` starts two ranks by itself.  Rehearsed on one GPU: both ranks share device 0 and talk over
+gloo (LVGPU_BENCH_BACKEND=gloo LVGPU_BENCH_ONE_DEVICE=1), so the numbers mean nothing; the control flow -- spawn,
+frame sharding, barrier, max over ranks, one JSON line from rank 0, exit code -- is what is exercised."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, **extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"LVGPU_BENCH_BACKEND": "gloo", "LVGPU_BENCH_ONE_DEVICE": "1"})
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True,
+                          timeout=420)
+
+
+def test_gpus_2_runs_two_ranks(gpu):
+    p = _bench("--gpus", "2", "--frames-per-gpu", "64", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                 # rank 0 alone prints
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["frames_per_gpu"] == 64 and r["config"]["total_frames"] == 128
+    assert len(r["per_rank_Mpx_s"]) == 2 and all(v > 0 for v in r["per_rank_Mpx_s"])
+    assert r["roofline"]["kernel"] == "k_tile(fused)"
+    assert "cpu_baseline" not in r and "eighth_gpu" not in r   # rank 0 at N = 1 only
+    assert r["value"] > 0 and abs(r["value"] - 2 * 64 * 480 * 320 * 3 / (r["ms_per_step"] * 3e-3) / 1e6) < 0.01 * r["value"]
+
+
+def test_a_failing_rank_fails_the_command(gpu):
+    p = _bench("--gpus", "2", "--frames-per-gpu", "64", "--steps", "1", "--warmup", "1", "--workload", "scene", "--width", "64")
+    assert p.returncode != 0                               # the scene workload rejects other sizes: every rank asserts
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]

@@ -200,3 +200,47 @@ def test_results_do_not_depend_on_the_streams_cu_mask(gpu):
             assert torch.equal(res[0][0], res[0][2])
     finally:
         ms.close()
+
+
+def test_config4_65536_frames_and_their_shards(gpu, oracle):
+    """The 65 536-frame batch that is sharded per frame over 2/4/8 GPUs, resident on one GPU (80 GB): the fused
+    blend + 90-degree flush in one launch, checked through properties that hold for every frame, against the oracle on
+    sampled frames, and against the same frames processed as the shards rank g of G would hold (inputs are a function
+    of the global frame index, so a shard computed on its own must equal its slice of the whole batch)."""
+    from vvc_amd import sharding
+    NT = 65536
+    area = (0, 0, W - 1, H - 1)
+    dst = gpu.synth(gpu.SYNTH_U16, 0x5EED0001, 0, (NT, H, W))
+    src = gpu.synth(gpu.SYNTH_ARGB_UI, 0x5EED0002, 0, (NT, H, W))
+    out = torch.empty((NT, W, H), dtype=torch.int16, device="cuda")
+    gpu.blend_flush(gpu.DrawCtx(dst), gpu.BlendDsc(area, src_buf=src, src_format=gpu.SRC_ARGB8888), gpu.LV_DISP_ROT_90,
+                    out=out)
+    assert gpu.last_kernel() == "k_tile(fused)"
+    torch.cuda.synchronize()
+    step = 2048
+    for lo in range(0, NT, step):
+        d, s, o = dst[lo:lo + step], src[lo:lo + step], out[lo:lo + step]
+        # the panel image is the rotated draw buffer: out[x][H-1-y] = dst[y][x]
+        assert torch.equal(o, d.flip(1).transpose(1, 2)), lo
+        before = gpu.synth(gpu.SYNTH_U16, 0x5EED0001, lo * PX, (step, H, W))
+        a = (s >> 24) & 0xFF
+        assert torch.equal(d[a == 0], before[a == 0]), lo          # alpha 0 leaves the destination
+        c565 = gpu.color_from_rgb888(s & 0xFFFFFF, 1)
+        assert torch.equal(d[a == 255], c565[a == 255]), lo        # alpha 255 stores lv_color_make of the source
+        del before, a, c565
+    for f in (0, 1, 4095, 4096, 8191, 8192, 32767, 32768, 49152, 65535):   # shard borders for G = 2, 4, 8 among them
+        d = oracle.synth(oracle.SYNTH_U16, 0x5EED0001, f * PX, PX).copy()
+        s = oracle.synth(oracle.SYNTH_ARGB_UI, 0x5EED0002, f * PX, PX)
+        o = np.empty(PX, np.uint16)
+        oracle.argb_blend_flush_batch(d, s, o, W, H, 1, 1, 1, 1)
+        assert np.array_equal(dst[f].cpu().numpy().view(np.uint16).reshape(-1), d), f
+        assert np.array_equal(out[f].cpu().numpy().view(np.uint16).reshape(-1), o), f
+    for g, G in ((5, 8), (1, 4), (1, 2)):
+        lo, hi = sharding.frame_range(g, G, NT)
+        n = hi - lo
+        assert n * G == NT
+        sd = gpu.synth(gpu.SYNTH_U16, 0x5EED0001, lo * PX, (n, H, W))
+        ss = gpu.synth(gpu.SYNTH_ARGB_UI, 0x5EED0002, lo * PX, (n, H, W))
+        so = gpu.blend_flush(gpu.DrawCtx(sd), gpu.BlendDsc(area, src_buf=ss, src_format=gpu.SRC_ARGB8888), gpu.LV_DISP_ROT_90)
+        assert torch.equal(sd, dst[lo:hi]) and torch.equal(so, out[lo:hi]), (g, G)
+        del sd, ss, so

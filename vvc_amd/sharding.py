@@ -51,6 +51,15 @@ def max_over_ranks(dist, values):
     return [float(v) for v in t]
 
 
+def gather_floats(dist, value):
+    """One float per rank, in rank order, on every rank (host-side, tiny)."""
+    if dist is None:
+        return [float(value)]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, float(value))
+    return parts
+
+
 def sum_over_ranks_u64(dist, value):
     """Sum modulo 2^64 of one unsigned 64-bit value per rank (checksum of checksums; host-side, tiny)."""
     if dist is None:
