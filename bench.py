@@ -12,7 +12,7 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
     clipped_small, clipped_large   lv_draw_sw_blend of a per-frame RGB565 image + A8 mask over a clipped,
                            misaligned area (201x101 at an odd x / 468x296 at x = 3) of 480x320 buffers; pixels
                            counted are the area's (7 B/px)
-    fill_translucent       fill_normal without mask at opa 128 (premultiplied formula + scan-order pre-pass), 4 B/px
+    fill_translucent       fill_normal without mask, translucent (premultiplied formula + scan-order pre-pass), 4 B/px
     fill_opaque / map_opaque   lv_color_fill per row (2 B/px, write only) / row copy (4 B/px)
     fill_masked            fill_normal with an A8 mask at opa 255 (5 B/px)
     fill_masked_argb       the same into a 3-byte ARGB8565 draw buffer (screen_transp): 3 R + 3 W + 1 R = 7 B/px
@@ -369,9 +369,10 @@ def main(argv=None):
         a8 = lvgpu.synth(mask_kind, SEED_MASK, lo * px_per_frame, (n, bh, bw))
         dsc = lvgpu.BlendDsc(ba, src_buf=src16, mask_buf=a8, opa=255)
     elif wl == "fill_translucent":
-        # colour 0x1234 at opa 128: lv_color_mix and lv_color_mix_premult disagree on black, so the scan-order
-        # pre-pass (first non-black pixel of every frame) runs
-        dsc = lvgpu.BlendDsc(area, color=0x1234, opa=128)
+        # a colour / opacity pair for which lv_color_mix and lv_color_mix_premult disagree on black (about one pair in
+        # twenty does), so that the scan-order pre-pass (first non-black pixel of every frame) runs
+        color, opa = (0xD67F, 137) if args.swap else (0x2EDE, 103)
+        dsc = lvgpu.BlendDsc(area, color=color, opa=opa)
     elif wl == "fill_opaque":
         dsc = lvgpu.BlendDsc(area, color=0x1234, opa=255)
     elif wl == "map_opaque":
@@ -464,7 +465,7 @@ def main(argv=None):
                     % (wl, args.mask, list(ba), W, H, args.swap, n))
         elif wl.startswith("fill") or wl == "map_opaque":
             desc = ("%s: %s over whole %dx%d buffers, LV_COLOR_16_SWAP %d, %d frames per GPU"
-                    % (wl, {"fill_translucent": "fill_normal, no mask, opa 128 (premultiplied formula + scan-order pre-pass)",
+                    % (wl, {"fill_translucent": "fill_normal, no mask, opa %d (premultiplied formula + scan-order pre-pass)" % (137 if args.swap else 103),
                             "fill_opaque": "fill_normal, no mask, opa 255 (lv_color_fill)",
                             "map_opaque": "map_normal, no mask, opa 255 (row copy)",
                             "fill_masked": "fill_normal with an A8 mask (%s), opa 255" % args.mask,
