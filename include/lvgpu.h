@@ -132,6 +132,20 @@ typedef struct {
 
 int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
 
+/*
+ * lvgpu_blend_batch for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same results; the one
+ * piece of device memory lvgpu_blend_batch allocates per call -- one 32-bit scan index per frame, needed by the
+ * translucent unmasked fill (lv_draw_sw_blend.c:261-287) to reproduce the reference's first-pixel cache -- lives in a
+ * fixed array of LVGPU_NOALLOC_MAX_FRAMES entries (256 KB) that is part of the library's device image, so every GPU
+ * the library runs on holds one until the process ends.  The call performs no hipMalloc / hipFree of any kind.
+ * n_frames > LVGPU_NOALLOC_MAX_FRAMES is LVGPU_ERR_ARG whatever the descriptor (split the batch).  All calls on one
+ * GPU share that GPU's array: calls that may run at the same time on one GPU (different streams, different host
+ * threads) race on it; calls on one stream, or otherwise ordered, are fine.
+ */
+#define LVGPU_NOALLOC_MAX_FRAMES 65536
+int lvgpu_blend_batch_noalloc(const lvgpu_blend_batch_t * dsc, void * stream);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Flush: the copy / rotate of lvgl_port_flush_callback over a batch of frames                                  */
 /* ------------------------------------------------------------------------------------------------------------ */

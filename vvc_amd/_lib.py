@@ -99,6 +99,7 @@ def lib():
         "lvgpu_memset": (C.c_int, [vp, C.c_int, sz, vp]),
         "lvgpu_stream_synchronize": (C.c_int, [vp]),
         "lvgpu_blend_batch": (C.c_int, [C.POINTER(BlendBatch), vp]),
+        "lvgpu_blend_batch_noalloc": (C.c_int, [C.POINTER(BlendBatch), vp]),
         "lvgpu_flush_rotate_batch": (C.c_int, [C.POINTER(FlushBatch), vp]),
         "lvgpu_blend_flush_batch": (C.c_int, [C.POINTER(BlendFlushBatch), vp]),
         "lvgpu_flush_chunks": (C.c_int, [C.POINTER(Area), C.c_int32, C.c_int32, C.c_int32, C.c_uint32,

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,6 +15,12 @@
 #include "lvgpu_list.hpp"
 
 using namespace lvgpu;
+
+// Scratch of lvgpu_blend_batch_noalloc: per frame, the scan index of the first non-black pixel of the area (what
+// prepare_first_nb otherwise keeps in a stream-ordered allocation).  Every GPU holds its own copy of the array until
+// the process ends.  In host code the name below is only a handle for hipGetSymbolAddress: the address kernels and
+// hipMemsetAsync get is the per-device pointer kept in g_scratch_ptr.
+static __device__ __align__(256) uint32_t scratch[LVGPU_NOALLOC_MAX_FRAMES];
 
 namespace {
 
@@ -66,6 +73,26 @@ int src_bytes_per_px(int fmt)
         case LVGPU_SRC_ARGB8565: return 3;
         default: return 0;
     }
+}
+
+// Device address of `scratch` on the current device, looked up once per device with that device current.
+constexpr int MAX_DEVICES = 64;
+uint32_t * g_scratch_ptr[MAX_DEVICES];
+std::mutex g_scratch_mutex;
+int scratch_on_current_device(uint32_t ** out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if(dev < 0 || dev >= MAX_DEVICES) return fail(LVGPU_ERR_ARG, "device %d: only devices 0..%d are supported", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if(g_scratch_ptr[dev] == nullptr) {
+        uint32_t * p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch)));
+        if(p == nullptr) return fail(LVGPU_ERR_HIP, "hipGetSymbolAddress(scratch) returned NULL on device %d", dev);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return LVGPU_OK;
 }
 
 enum Resolve { R_NOOP = 0, R_WORK = 1 };
@@ -171,20 +198,34 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
 
 // min index of the first non-black pixel per frame, only needed when the two formulas of the translucent fill
 // disagree on black (otherwise every black pixel gets the same value either way).
-int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** scratch)
+// provided: device memory for n_frames indices that the caller owns (nothing is allocated then and *owned stays
+// nullptr); otherwise the indices live in a stream-ordered allocation that the caller frees (hipFreeAsync) after the
+// blend kernel has been launched.
+int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** owned, uint32_t * provided = nullptr)
 {
-    *scratch = nullptr;
+    *owned = nullptr;
     if(a.opa_mode != OM_FILL_PREMULT) return LVGPU_OK;
     const uint32_t pm_black = ((((a.pf.pm_r * 0x8081u) >> 23) & 0x1Fu) << 11) | ((((a.pf.pm_g * 0x8081u) >> 23) & 0x3Fu) << 5) |
                               (((a.pf.pm_b * 0x8081u) >> 23) & 0x1Fu);
     if(pm_black == a.pf.first_res) return LVGPU_OK;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(scratch), (size_t)a.n_frames * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(*scratch, 0xFF, (size_t)a.n_frames * sizeof(uint32_t), st));
-    const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
-    dim3 grid(std::min<uint32_t>((area + 255) / 256, 64), std::min<uint32_t>(a.n_frames, 65535));
-    hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, *scratch);
-    HIP_TRY(hipGetLastError());
-    a.first_nb = *scratch;
+    uint32_t * buf = provided;
+    if(buf == nullptr) {
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&buf), (size_t)a.n_frames * sizeof(uint32_t), st));
+        *owned = buf;
+    }
+    hipError_t e = hipMemsetAsync(buf, 0xFF, (size_t)a.n_frames * sizeof(uint32_t), st);
+    if(e == hipSuccess) {
+        const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
+        dim3 grid(std::min<uint32_t>((area + 255) / 256, 64), std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, buf);
+        e = hipGetLastError();
+    }
+    if(e != hipSuccess) {
+        if(*owned) (void)hipFreeAsync(*owned, st);
+        *owned = nullptr;
+        return fail(LVGPU_ERR_HIP, "first-non-black pass: %s", hipGetErrorString(e));
+    }
+    a.first_nb = buf;
     return LVGPU_OK;
 }
 
@@ -394,7 +435,7 @@ bool argb_linear_ok(const BlendArgs & a, int fmt)
     return true;
 }
 
-int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
+int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false, uint32_t * first_nb_buf = nullptr)
 {
     if(argb_dst) {
         if(argb_linear_ok(a, fmt)) {
@@ -404,8 +445,8 @@ int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
         g_last_kernel = "k_blend_argb_dst";
         return dispatch_src<LaunchArgbDst>(fmt, a, st);
     }
-    uint32_t * scratch = nullptr;
-    int rc = prepare_first_nb(a, st, &scratch);
+    uint32_t * owned = nullptr;
+    int rc = prepare_first_nb(a, st, &owned, first_nb_buf);
     if(rc != LVGPU_OK) return rc;
     if(linear_ok(a, fmt)) {
         g_last_kernel = "k_blend_linear";
@@ -415,7 +456,10 @@ int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false)
         g_last_kernel = "k_blend_rows";
         rc = dispatch_src<LaunchRows>(fmt, a, st);
     }
-    if(scratch) HIP_TRY(hipFreeAsync(scratch, st));
+    if(owned) {  // in stream order: after the kernels that read it
+        const hipError_t e_free = hipFreeAsync(owned, st);
+        if(rc == LVGPU_OK && e_free != hipSuccess) return fail(LVGPU_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e_free));
+    }
     return rc;
 }
 
@@ -981,7 +1025,8 @@ int lvgpu_init(int device)
     if(strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(LVGPU_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
     HIP_TRY(hipFree(nullptr));
-    return LVGPU_OK;
+    uint32_t * p = nullptr;
+    return scratch_on_current_device(&p);  // so that lvgpu_blend_batch_noalloc finds it without a lookup of its own
 }
 
 int lvgpu_malloc(void ** p, size_t bytes)
@@ -1026,6 +1071,22 @@ int lvgpu_blend_batch(const lvgpu_blend_batch_t * d, void * stream)
     return launch_blend(a, d->src_format, (hipStream_t)stream, d->dst_argb8565 != 0);
 }
 
+int lvgpu_blend_batch_noalloc(const lvgpu_blend_batch_t * d, void * stream)
+{
+    BlendArgs a;
+    lvgpu_area_t area;
+    g_last_kernel = "";
+    if(d != nullptr && d->n_frames > LVGPU_NOALLOC_MAX_FRAMES)
+        return fail(LVGPU_ERR_ARG, "lvgpu_blend_batch_noalloc takes at most %d frames per call (%d given); split the batch or use "
+                    "lvgpu_blend_batch", LVGPU_NOALLOC_MAX_FRAMES, d->n_frames);
+    int r = resolve_blend(d, a, area);
+    if(r <= 0) return r;
+    uint32_t * buf = nullptr;
+    r = scratch_on_current_device(&buf);
+    if(r != LVGPU_OK) return r;
+    return launch_blend(a, d->src_format, (hipStream_t)stream, d->dst_argb8565 != 0, buf);
+}
+
 int lvgpu_flush_rotate_batch(const lvgpu_flush_batch_t * d, void * stream)
 {
     g_last_kernel = "";
@@ -1063,8 +1124,8 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
         a.swap_out = d->swap_bytes ? 1 : 0;
         const bool ok = transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format);
         if(ok) {
-            uint32_t * scratch = nullptr;
-            int rc = prepare_first_nb(a, st, &scratch);
+            uint32_t * owned = nullptr;
+            int rc = prepare_first_nb(a, st, &owned);
             if(rc != LVGPU_OK) return rc;
             if(transposing && wants_strip(a)) {
                 g_last_kernel = "k_strip(fused)";
@@ -1078,7 +1139,10 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
                 g_last_kernel = "k_blend_linear(fused)";
                 rc = dispatch_src<LaunchLinear>(b.src_format, a, st);
             }
-            if(scratch) HIP_TRY(hipFreeAsync(scratch, st));
+            if(owned) {
+                const hipError_t e_free = hipFreeAsync(owned, st);
+                if(rc == LVGPU_OK && e_free != hipSuccess) return fail(LVGPU_ERR_HIP, "hipFreeAsync: %s", hipGetErrorString(e_free));
+            }
             return rc;
         }
         a.out = nullptr;

@@ -147,6 +147,12 @@ def lv_draw_sw_blend(ctx, dsc, stream=None):
     check(_lib.lib().lvgpu_blend_batch(C.byref(b), _stream(stream)))
 
 
+def lv_draw_sw_blend_noalloc(ctx, dsc, stream=None):
+    """lv_draw_sw_blend through lvgpu_blend_batch_noalloc: same result, no device allocation inside the call."""
+    b = _fill_batch(ctx, dsc)
+    check(_lib.lib().lvgpu_blend_batch_noalloc(C.byref(b), _stream(stream)))
+
+
 def flush_rotate(inp, rotation, swap_bytes=0, out=None, stream=None):
     """The copy/rotate of lvgl_port_flush_callback for a batch [n, H, W] of rendered frames.  Returns the panel
     images, [n, W, H] for 90/270 degrees and [n, H, W] otherwise."""
