@@ -1,14 +1,19 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun) from the repository root: rocprofv3 kernel-trace statistics and the two
-# PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, they do not fit one pass) for each bench workload.
+# Run on the GPU box (through gpurun) from the repository root: for each bench workload the rocprofv3 kernel-trace
+# statistics and the two PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, they do not fit one pass).
 # Output goes to gpurun_out/prof/<workload>/{kt,fetch,write}; tools/summarize_profiles.py turns it into profiles/.
-set -e
+#   tools/collect_profiles.sh [workload ...]       (default: every workload below; "<name>_swap0" = --swap 0)
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
-for w in blend_flush blend rotate; do
+ALL="blend_flush blend_flush_swap0 blend rotate blend_flush_rgb565a8 blend_rgb565a8 blend_flush_4k clipped_small clipped_large fill_translucent fill_opaque map_opaque fill_masked fill_masked_argb scene"
+for w in ${@:-$ALL}; do
+  name=${w%_swap0}
+  extra=""
+  [ "$name" != "$w" ] && extra="--swap 0"
+  rm -rf $OUT/$w
   mkdir -p $OUT/$w
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/kt -- python3 bench.py --workload $w --no-cpu-baseline --no-eighth > $OUT/$w/kt.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$w/fetch -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-eighth > $OUT/$w/fetch.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$w/write -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-eighth > $OUT/$w/write.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w/kt -- python3 bench.py --workload $name $extra --no-cpu-baseline --no-eighth > $OUT/$w/kt.log 2>&1 || { echo "$w: kernel trace failed"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$w/fetch -- python3 bench.py --workload $name $extra --steps 3 --warmup 1 --no-cpu-baseline --no-eighth > $OUT/$w/fetch.log 2>&1 || { echo "$w: FETCH_SIZE pass failed"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$w/write -- python3 bench.py --workload $name $extra --steps 3 --warmup 1 --no-cpu-baseline --no-eighth > $OUT/$w/write.log 2>&1 || { echo "$w: WRITE_SIZE pass failed"; exit 1; }
   echo "$w done"
 done

@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof (see tools/collect_profiles.sh) into the committed summaries under profiles/<round>/ and
-profiles/traffic.json (HBM bytes per launch of the dominant kernel, which bench.py reports as roofline.traffic).
+profiles/traffic.json (HBM bytes per launch of each workload's dominant kernel, which bench.py reports as
+roofline.traffic when the kernel sources still are the ones that were profiled).
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced streaming read at half its size
-(128-byte requests tallied as 64 bytes), so reads are doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
+(128-byte requests tallied as 64 bytes), so reads are doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
+
+    python3 tools/summarize_profiles.py r02
+"""
+import collections
 import csv
 import glob
 import json
@@ -11,56 +16,115 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (workload table, kernel-source digest; imports no GPU code)
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-KERNEL = {"blend_flush": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile"}
-BPP = {"blend_flush": 10, "blend": 8, "rotate": 4}
-traffic = {}
+# dominant kernel of each workload (a substring of the demangled name in rocprofv3's tables)
+KERNEL = {"blend_flush": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile", "blend_flush_rgb565a8": "k_tile",
+          "blend_rgb565a8": "k_blend_linear", "blend_flush_4k": "k_strip", "clipped_small": "k_blend_rows",
+          "clipped_large": "k_blend_rows", "fill_translucent": "k_blend_linear", "fill_opaque": "k_blend_linear",
+          "map_opaque": "k_blend_linear", "fill_masked": "k_blend_linear", "fill_masked_argb": "k_blend_argb_linear",
+          "scene": "k_blend_list"}
 
 
 def newest(pattern):
     """gpurun merges every run's files into the same directories (named by process id): take the latest."""
-    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return files[-1:]
 
 
-for w, kname in KERNEL.items():
-    d = os.path.join(src, w)
-    if not os.path.isdir(d):
+def bench_line(path):
+    try:
+        for line in open(path):
+            if line.startswith("{"):
+                return json.loads(line)
+    except OSError:
+        pass
+    return None
+
+
+traffic = {}
+table = []
+for w in sorted(os.listdir(src)) if os.path.isdir(src) else []:
+    name = w[:-6] if w.endswith("_swap0") else w
+    if name not in KERNEL:
         continue
-    stats = newest(os.path.join(d, "kt", "*", "*_kernel_stats.csv"))
+    kname = KERNEL[name]
+    d = os.path.join(src, w)
+    line = bench_line(os.path.join(d, "kt.log"))
+    stats = newest(os.path.join(d, "kt", "**", "*_kernel_stats.csv"))
+    avg_ns = calls = None
+    best_t = 0.0
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(dst, "%s_kernel_stats.csv" % w), "w") as f:
             csv.writer(f).writerows(rows)
+        hdr = rows[0]
+        for r in rows[1:]:
+            rec = dict(zip(hdr, r))
+            if kname in rec.get("Name", ""):
+                # several instantiations may match (warm-up synth kernels do not): take the one with the most time
+                t = float(rec["TotalDurationNs"])
+                if avg_ns is None or t > best_t:
+                    best_t, avg_ns, calls = t, float(rec["AverageNs"]), int(rec["Calls"])
     vals = {}
     for c in ("fetch", "write"):
-        files = newest(os.path.join(d, c, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(d, c, "**", "*_counter_collection.csv"))
         if not files:
             continue
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0])) if kname in r["Kernel_Name"]]
-        if v:
-            vals[c] = sum(v) / len(v)
+        per_kernel = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            per_kernel[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        match = {k: v for k, v in per_kernel.items() if kname in k}
+        if match:
+            k_big = max(match, key=lambda k: sum(match[k]))
+            vals[c] = sum(match[k_big]) / len(match[k_big])
+    if line is None:
+        continue
+    bpp, _w0, _h0, _n0 = bench.WORKLOADS[name]
+    n = line["config"]["frames_per_gpu"]
+    px_launch = line["roofline"]["achieved"] * 1e9 * line["roofline"]["launch_ms"] * 1e-3 / bpp   # pixels per launch
+    summ = {"workload": w, "command": "python3 bench.py --workload %s%s --no-cpu-baseline --no-eighth" %
+            (name, " --swap 0" if w != name else ""), "config": line["config"]["workload"], "kernel": kname,
+            "algorithmic_bytes_per_px": bpp, "algorithmic_bytes_per_launch": round(bpp * px_launch),
+            "bench_launch_ms(HIP events, unprofiled-equivalent run under the kernel trace)": line["roofline"]["launch_ms"],
+            "bench_frac_of_8TBs": line["roofline"]["frac"]}
+    if avg_ns is not None:
+        summ["kernel_trace_avg_ns"] = avg_ns
+        summ["kernel_trace_calls"] = calls
+        summ["kernel_trace_GBs"] = round(bpp * px_launch / avg_ns, 1)
+        summ["kernel_trace_frac_of_8TBs"] = round(bpp * px_launch / avg_ns / 8000.0, 4)
     if len(vals) == 2:
         rd, wr = vals["fetch"] * 1024 * 2, vals["write"] * 1024
-        px = 480 * 320 * 4096
-        summ = {"workload": w, "kernel": kname, "FETCH_SIZE_KiB_avg_per_launch": vals["fetch"],
-                "WRITE_SIZE_KiB_avg_per_launch": vals["write"], "hbm_read_bytes_per_launch(FETCH_SIZE*1024*2)": rd,
-                "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                "algorithmic_bytes_per_launch": BPP[w] * px, "traffic_over_algorithmic": (rd + wr) / (BPP[w] * px)}
-        json.dump(summ, open(os.path.join(dst, "%s_pmc_summary.json" % w), "w"), indent=1)
-        traffic[w] = rd + wr
-        print(w, "traffic/algorithmic = %.3f" % summ["traffic_over_algorithmic"])
-if traffic:
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        summ.update({"FETCH_SIZE_KiB_avg_per_launch": vals["fetch"], "WRITE_SIZE_KiB_avg_per_launch": vals["write"],
+                     "hbm_read_bytes_per_launch(FETCH_SIZE*1024*2)": rd, "hbm_write_bytes_per_launch": wr,
+                     "hbm_bytes_per_launch": rd + wr,
+                     "traffic_over_algorithmic": round((rd + wr) / (bpp * px_launch), 4)})
+        traffic[w] = {"hbm_bytes_per_launch": rd + wr, "frames": n}
+    json.dump(summ, open(os.path.join(dst, "%s_pmc_summary.json" % w), "w"), indent=1)
+    table.append((w, kname, summ.get("kernel_trace_avg_ns"), summ.get("kernel_trace_frac_of_8TBs"), summ.get("traffic_over_algorithmic")))
 
-# display-list kernel (tools/collect_list_profile.sh): kernel stats + HBM traffic + issue counters in one summary
+for w, k, ns, frac, tr in table:
+    print("%-24s %-20s avg %10s ns  %s of 8 TB/s  traffic/algorithmic %s" % (w, k, "%.0f" % ns if ns else "-", frac, tr))
+
+if traffic:
+    shapes = {}
+    for w in traffic:
+        name = w[:-6] if w.endswith("_swap0") else w
+        _bpp, W0, H0, _n0 = bench.WORKLOADS[name]
+        traffic[w]["shape"] = [traffic[w].pop("frames"), W0, H0]
+    json.dump({"source": "profiles/%s, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled" % rnd,
+               "kernel_sources_sha": bench.kernel_sources_sha(), "workloads": traffic},
+              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+
+# display-list kernel with its issue counters (tools/collect_list_profile.sh): kept as in round 1
 lsrc = os.path.join(src, "list")
 if os.path.isdir(lsrc):
-    import collections
-    st = newest(os.path.join(lsrc, "kt", "*", "*_kernel_stats.csv"))
+    st = newest(os.path.join(lsrc, "kt", "**", "*_kernel_stats.csv"))
     if st:
         rows = list(csv.reader(open(st[0])))
         with open(os.path.join(dst, "list_scene2_kernel_stats.csv"), "w") as f:
@@ -68,7 +132,7 @@ if os.path.isdir(lsrc):
     out = {"workload": "display list: golden LVGL scene 2 (1649 descriptors, 432119 drawn px per frame) replayed over 4096 "
                        "frames of 480x320 + fused 90-degree flush", "kernel": "k_blend_list"}
     for c in ("fetch", "write", "sq"):
-        files = newest(os.path.join(lsrc, c, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(lsrc, c, "**", "*_counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)
@@ -82,4 +146,3 @@ if os.path.isdir(lsrc):
         out["hbm_write_bytes_per_launch"] = out["WRITE_SIZE_avg_per_launch"] * 1024
         out["minimum_bytes_per_launch(2 B dst write + 2 B panel write per px)"] = 4 * 480 * 320 * 4096
     json.dump(out, open(os.path.join(dst, "list_scene2_pmc_summary.json"), "w"), indent=1)
-    print("list: VALU wave-instructions per launch %.0f" % out.get("SQ_INSTS_VALU_avg_per_launch", float("nan")))
