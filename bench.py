@@ -395,15 +395,18 @@ def main(argv=None):
                                        blend_mode=r["blend_mode"]))
         blist = lvgpu.BlendList(ctx, dscs).compile(flush=True, rotation=rot, swap_bytes=swap_bytes)  # planned once
 
+    # the descriptor is marshalled once: the clipped-area kernels finish faster than Python fills a ctypes struct
+    prepared = None
+    if dsc is not None:
+        prepared = (lvgpu.PreparedBlend(ctx, dsc, rot, swap_bytes, out) if wants_out else lvgpu.PreparedBlend(ctx, dsc))
+
     def step(stream=None):
         if blist is not None:
             blist.replay(out=out, stream=stream)
         elif wl == "rotate":
             lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out, stream=stream)
-        elif wants_out:
-            lvgpu.blend_flush(ctx, dsc, rot, swap_bytes=swap_bytes, out=out, stream=stream)
         else:
-            lvgpu.lv_draw_sw_blend(ctx, dsc, stream=stream)
+            prepared.run(stream)
 
     # first step on fresh inputs: keep the first frames for the CPU cross-check
     step()

@@ -102,6 +102,12 @@ int lvgpu_stream_synchronize(void * stream);
  * Frame f uses dst + f*dst_frame_stride pixels, src + f*src_frame_stride pixels (0 = one image shared by all
  * frames), mask + f*mask_frame_stride bytes (0 = shared).
  *
+ * Memory touched: only the area's pixels are ever written.  The destination is read in aligned 16-byte words, so for an
+ * area whose rows do not begin or end on a 16-byte boundary up to 14 bytes beside the row, inside the same aligned
+ * 16-byte word, are read and discarded (device allocations are 256-byte granular, so such a word never leaves the
+ * allocation the pixels live in).  Source and mask reads stay between the first and the last pixel of the area's
+ * rows (stride included).
+ *
  * Semantics replaced: lv_draw_sw_blend gate (opa <= LV_OPA_MIN -> no-op; empty clip -> no-op, :95-106),
  * lv_draw_sw_blend_basic mask_res handling (:111-115), fill_normal (:242-375), map_normal (:641-734), and with
  * src_format ARGB8888/RGBA8888/ARGB8565 the colour/alpha split in front of them.  Results are bit-exact.

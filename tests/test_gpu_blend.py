@@ -216,10 +216,11 @@ def test_blend_argb8565_destination(gpu, oracle, swap):
 
 @pytest.mark.parametrize("swap", [1, 0])
 def test_blend_argb8565_destination_full_frames(gpu, oracle, swap):
-    """The same semantics over whole, aligned frames: the vector kernel (8 pixels = 24 bytes per lane)."""
+    """The same semantics over whole, aligned frames: the vector kernel (16 pixels = 48 bytes per lane; frames whose
+    pixel count is not a multiple of 16 take the per-pixel kernel)."""
     rng = np.random.default_rng(77 + swap)
     N = 3
-    for (W, H) in [(64, 24), (480, 320), (40, 5)]:
+    for (W, H) in [(64, 24), (480, 320), (40, 5), (48, 5), (1088, 3)]:
         area = (0, 0, W - 1, H - 1)
         for t in range(40 if W < 480 else 8):
             dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
@@ -240,4 +241,31 @@ def test_blend_argb8565_destination_full_frames(gpu, oracle, swap):
             gpu.lv_draw_sw_blend(ctx, dsc)
             assert np.array_equal(to_np(d, np.uint8), exp), (W, t, opa, mode, src is not None, mask is not None)
             if opa > 2:
-                assert gpu.last_kernel() == "k_blend_argb_linear"
+                assert gpu.last_kernel() == ("k_blend_argb_linear" if (W * H) % 16 == 0 else "k_blend_argb_dst")
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_argb8565_destination_every_alpha_pair(gpu, oracle, swap):
+    """lv_color_mix_with_alpha (lv_color.h:530-577) divides fg_opa * 255 by the resulting opacity; the kernels take a
+    reciprocal instead: every (destination alpha, foreground alpha) pair, through both ARGB8565 kernels."""
+    rng = np.random.default_rng(5 + swap)
+    H = W = 256
+    area = (0, 0, W - 1, H - 1)
+    for opa in (255, 254, 253, 200, 3):
+        dst = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+        dst[..., 2] = np.arange(256, dtype=np.uint8)[None, :, None]      # destination alpha = row
+        mask = np.broadcast_to(np.arange(256, dtype=np.uint8)[None, None, :], (2, H, W)).copy()  # mask = column
+        src = rng.integers(0, 65536, (2, H, W), dtype=np.uint16)
+        for use_src in (False, True):
+            color = int(rng.integers(0, 65536))
+            for clip, kernel in ((area, "k_blend_argb_linear"), ((1, 0, W - 1, H - 1), "k_blend_argb_dst")):
+                exp = dst.copy()
+                for f in range(2):
+                    oracle.blend(exp[f], area, clip, area, src=src[f] if use_src else None, color=color, mask=mask[f], opa=opa,
+                                 swap=swap, screen_transp=1)
+                d = to_dev(dst)
+                ctx = gpu.DrawCtx(d, area, clip, color_16_swap=swap, screen_transp=1)
+                gpu.lv_draw_sw_blend(ctx, gpu.BlendDsc(area, src_buf=to_dev(src) if use_src else None, color=color,
+                                                       mask_buf=to_dev(mask), opa=opa))
+                assert gpu.last_kernel() == kernel
+                assert np.array_equal(to_np(d, np.uint8), exp), (opa, use_src, kernel)

@@ -215,9 +215,14 @@ int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** owned, uint32_t 
     }
     hipError_t e = hipMemsetAsync(buf, 0xFF, (size_t)a.n_frames * sizeof(uint32_t), st);
     if(e == hipSuccess) {
+        // one block per frame when there are frames enough to fill the chip, otherwise several segments per frame
+        // (an all-black 4K canvas is 16 MB for its blocks to walk); a segment is a whole number of 1024-pixel pieces
         const uint32_t area = (uint32_t)a.w * (uint32_t)a.h;
-        dim3 grid(std::min<uint32_t>((area + 255) / 256, 64), std::min<uint32_t>(a.n_frames, 65535));
-        hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, buf);
+        const uint32_t pieces = (area + 1023u) / 1024u;
+        const uint32_t want = std::max<uint32_t>(1u, std::min<uint32_t>((2048u + a.n_frames - 1) / a.n_frames, (pieces + 3u) / 4u));
+        const uint32_t seg_px = ((pieces + want - 1) / want) * 1024u;
+        dim3 grid((area + seg_px - 1) / seg_px, std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, seg_px, buf);
         e = hipGetLastError();
     }
     if(e != hipSuccess) {
@@ -252,7 +257,7 @@ int dispatch_src(int fmt, Args &&... args)
 // 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied only to the
 // launches named at its uses, on streams that own the whole device.
 constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
-                   ROWS_PAD_LDS = 24 * 1024, ARGB_PAD_LDS = 16 * 1024;
+                   ARGB_PAD_LDS = 16 * 1024;  // (unused while the ARGB8565 kernel is being retuned)
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     static thread_local int dev_cached = -1, dev_cus = 0;
@@ -321,11 +326,12 @@ template <int SRC>
 struct LaunchArgbLinear {
     static int run(const BlendArgs & a, hipStream_t st)
     {
-        const uint32_t gpf = (uint32_t)(((size_t)a.w * a.h) / 8);
-        const uint32_t cpf = (gpf + 256 * ARGB_UNROLL - 1) / (256 * ARGB_UNROLL);
+        const uint32_t gpf = (uint32_t)(((size_t)a.w * a.h) / 16);
+        const uint32_t cpf = (gpf + ARGB_BLOCK_GROUPS - 1) / ARGB_BLOCK_GROUPS;
         const uint64_t blocks = (uint64_t)cpf * a.n_frames;
         if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const uint32_t pad = a.has_mask ? residency_pad(st, ARGB_PAD_LDS) : 0;  // masked fill 50.3 -> 54.2 % of peak
+        uint32_t pad = 0;
+        if(getenv("LVGPU_DEV_ARGB_PAD")) pad = (uint32_t)atoi(getenv("LVGPU_DEV_ARGB_PAD"));
         hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
@@ -353,40 +359,33 @@ template <int SRC>
 struct LaunchRows {
     static int run(const BlendArgs & a, hipStream_t st)
     {
-        const uint32_t gmax = ((uint32_t)a.w + 7 + 7) / 8;  // groups per row for the worst row alignment
-        uint64_t lanes = (uint64_t)gmax * (uint32_t)a.h;
         RowsMap map;
         memset(&map, 0, sizeof(map));
+        map.groups_per_row = ((uint32_t)a.w + 7 + 7) / 8;  // the worst row alignment
         if((a.dst_stride % 8) == 0 && (a.dst_fs % 8) == 0) {  // one alignment for every row of every frame
             const uint32_t off = (uint32_t)((reinterpret_cast<uintptr_t>(a.dst) >> 1) & 7u);
-            map.uniform = 1;
-            map.k_lo = off ? 1u : 0u;
-            map.k_hi = ((uint32_t)a.w + off) / 8;
-            if(map.k_hi < map.k_lo) map.k_hi = map.k_lo = 0;  // no whole group at all: group 0 holds the whole row
-            map.n_whole_row = map.k_hi - map.k_lo;
-            map.edge_lo = (map.k_lo > 0 || map.k_hi == 0) ? 1 : 0;
-            map.edge_hi = (map.k_hi > 0 && map.k_hi * 8 < (uint32_t)a.w + off) ? 1 : 0;
-            lanes = (uint64_t)map.n_whole_row * (uint32_t)a.h + 2ull * (uint32_t)a.h;
+            map.groups_per_row = (off + (uint32_t)a.w + 7) / 8;
         }
-        dim3 grid((uint32_t)((lanes + 255) / 256), std::min<uint32_t>(a.n_frames, 65535));
-        // residency cap as for the full-frame kernels: +3-10 % on areas of 20 000 px and more, -5 % on a 32x32 one
-        const bool plain = a.blend_fn == BF_NORMAL && a.opa_mode != OM_FILL_PREMULT;
-        const uint32_t rows_pad = plain && (uint64_t)a.w * (uint32_t)a.h >= 8192 ? residency_pad(st, ROWS_PAD_LDS) : 0;
+        map.src_span = (long long)(a.h - 1) * a.src_stride + a.w;
+        map.mask_span = (long long)(a.h - 1) * a.mask_stride + a.w;
+        const uint64_t lanes = (uint64_t)map.groups_per_row * (uint32_t)a.h;
+        dim3 grid((uint32_t)((lanes + 256 * ROWS_UNROLL - 1) / (256 * ROWS_UNROLL)), std::min<uint32_t>(a.n_frames, 65535));
+        const uint32_t rows_pad = 0;  // no residency cap: with a row's edges handled in its own wavefronts it only loses
         // the combinations resolve_blend produces with the normal blend function; everything else decides per pixel
         constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
         const bool normal = a.blend_fn == BF_NORMAL;
         if(normal && a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), rows_pad, st, a, map);
         else if(normal && a.opa_mode == OM_CONST && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), rows_pad, st, a, map);
         else if(normal && a.opa_mode == OM_MASK && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), rows_pad, st, a, map);
         else if(normal && a.opa_mode == OM_FILL_MASK_OPA && SRC == SRC_FILL)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), rows_pad, st, a, map);
         else if(normal && a.opa_mode == OM_MAP_MASK_OPA && SRC != SRC_FILL && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), rows_pad, st, a, map);
         else
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), rows_pad, st, a, gmax, map);
+            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), rows_pad, st, a, map);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
@@ -416,12 +415,12 @@ bool tile_ok(const BlendArgs & a, int fmt)
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
 
-// The same question for a 3-byte destination: groups of 8 pixels are 24 bytes, accessed as three 8-byte words.
+// The same question for a 3-byte destination: groups of 16 pixels are 48 bytes = three 16-byte words.
 bool argb_linear_ok(const BlendArgs & a, int fmt)
 {
-    if(((size_t)a.w * a.h) % 8) return false;
+    if(((size_t)a.w * a.h) % 16) return false;
     if(a.h > 1 && a.dst_stride != a.w) return false;
-    if(!aligned(a.dst, 8) || ((a.dst_fs * 3) % 8)) return false;
+    if(!aligned(a.dst, 16) || ((a.dst_fs * 3) % 16)) return false;
     if(fmt != SRC_FILL) {
         if(a.h > 1 && a.src_stride != a.w) return false;
         const size_t bpp = src_bytes_per_px(fmt);
@@ -430,7 +429,7 @@ bool argb_linear_ok(const BlendArgs & a, int fmt)
     }
     if(a.mask) {
         if(a.h > 1 && a.mask_stride != a.w) return false;
-        if(!aligned(a.mask, 8) || (a.mask_fs % 8)) return false;
+        if(!aligned(a.mask, 16) || (a.mask_fs % 16)) return false;
     }
     return true;
 }

@@ -189,11 +189,32 @@ __device__ __forceinline__ uint4 blend_group_mix(const A & a, uint4 d, const uin
     return make_uint4(rw[0], rw[1], rw[2], rw[3]);
 }
 
+// The translucent unmasked fill (OM_FILL_PREMULT) over one 8-pixel group, two pixels per packed operation.  Only a
+// group that starts before the frame's first non-black pixel can hold pixels that still see the initial cache entry.
+template <class A>
+__device__ __forceinline__ uint4 blend_group_premult(const A & a, uint4 d, uint32_t scan0, uint32_t fnb)
+{
+    const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+    uint32_t rw[4];
+#pragma unroll
+    for(int i = 0; i < 4; i++) {
+        const uint32_t n = px_swap16x2_if(dw[i], a.swap);
+        uint32_t r = px_mix_premult_x2(a.pf, n);
+        if(scan0 < fnb) {
+            if((n & 0xFFFFu) == 0u && scan0 + 2u * i < fnb) r = (r & 0xFFFF0000u) | a.pf.first_res;
+            if((n >> 16) == 0u && scan0 + 2u * i + 1u < fnb) r = (r & 0x0000FFFFu) | (a.pf.first_res << 16);
+        }
+        rw[i] = px_swap16x2_if(r, a.swap);
+    }
+    return make_uint4(rw[0], rw[1], rw[2], rw[3]);
+}
+
 // Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
 template <int SRC, int OM, bool BLENDED, class A>
 __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
     if(OM == OM_OPAQUE && SRC == SRC_RGB565) return make_uint4(sw[0], sw[1], sw[2], sw[3]);  // same stored format
+    if(OM == OM_FILL_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     if(!BLENDED && (OM == OM_CONST || OM == OM_MASK || OM == OM_FILL_MASK_OPA || OM == OM_MAP_MASK_OPA))
         return blend_group_mix<SRC, OM>(a, d, sw, mk);
     uint32_t dw[4] = {d.x, d.y, d.z, d.w};
@@ -226,13 +247,16 @@ __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_
 //                either way; on a fraction of the CUs (32 of 256: +25 %) the shorter instruction stream is what counts.
 //   FAST_OPAQUE  fill_normal / map_normal without mask at opa >= LV_OPA_MAX (lv_draw_sw_blend.c:254-259, :655-660:
 //                lv_color_fill / lv_memcpy per row): the destination is only written, so it is not loaded either.
-enum FastPath : int { FAST_NONE = 0, FAST_MIX = 1, FAST_OPAQUE = 2 };
+//   FAST_PREMULT fill_normal without mask below LV_OPA_MAX (:261-287): the premultiplied formula in packed 16-bit
+//                arithmetic; per pixel it is bound by instruction issue (29 -> 15 lane instructions per pixel).
+enum FastPath : int { FAST_NONE = 0, FAST_MIX = 1, FAST_OPAQUE = 2, FAST_PREMULT = 3 };
 template <int SRC, class A>
 __host__ __device__ __forceinline__ int fast_path(const A & a)
 {
     constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
     if(SRC == SRC_COPY || a.blend_fn != BF_NORMAL) return FAST_NONE;
     if(a.opa_mode == OM_MASK) return FAST_MIX;
+    if(a.opa_mode == OM_FILL_PREMULT) return SRC == SRC_FILL ? FAST_PREMULT : FAST_NONE;
     if(a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha) return FAST_OPAQUE;
     return FAST_NONE;
 }
@@ -242,6 +266,7 @@ __device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, c
 {
     if(fast == FAST_MIX) return blend_group_mix<SRC, OM_MASK>(a, d, sw, mk);
     if(fast == FAST_OPAQUE) return blend_group_s<SRC, OM_OPAQUE, false>(a, d, sw, mk, scan0, fnb);
+    if(fast == FAST_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     return blend_group<SRC>(a, d, sw, mk, scan0, fnb);
 }
 
@@ -599,109 +624,130 @@ __device__ __forceinline__ void load_src_unaligned(const void * base, long long 
     }
 }
 
-// source colour (native) and alpha / mask of the pixel at area-relative (x, y) of frame f
+// The same words gathered pixel by pixel, for the pixels j in [j0, j1) only (the others stay zero): used where the
+// wide load would reach outside the rows of the source that belong to the area.
 template <int SRC>
-__device__ __forceinline__ void fetch_one_px(const BlendArgs & a, uint32_t f, uint32_t x, uint32_t y, uint32_t & fg, uint32_t & m)
+__device__ __forceinline__ void load_src_guarded(const void * base, long long px, int j0, int j1, uint32_t * sw)
 {
-    const size_t sp = (size_t)y * a.src_stride + x;
+#pragma unroll
+    for(int i = 0; i < SrcWords<SRC>::N; i++) sw[i] = 0;
     if(SRC == SRC_RGB565) {
-        uint32_t v = (reinterpret_cast<const uint16_t *>(a.src) + (long long)f * a.src_fs)[sp];
-        fg = a.swap ? px_swap16(v) : v;
+        const uint16_t * p = reinterpret_cast<const uint16_t *>(base) + px;
+#pragma unroll
+        for(int j = 0; j < 8; j++)
+            if(j >= j0 && j < j1) sw[j >> 1] |= (uint32_t)p[j] << ((j & 1) * 16);
     }
     else if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
-        uint32_t v = (reinterpret_cast<const uint32_t *>(a.src) + (long long)f * a.src_fs)[sp];
-        fg = SRC == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
-        m = v >> 24;
+        const uint32_t * p = reinterpret_cast<const uint32_t *>(base) + px;
+#pragma unroll
+        for(int j = 0; j < 8; j++)
+            if(j >= j0 && j < j1) sw[j] = p[j];
     }
     else if(SRC == SRC_ARGB8565) {
-        const uint8_t * p = reinterpret_cast<const uint8_t *>(a.src) + ((long long)f * a.src_fs + (long long)sp) * 3;
-        uint32_t v = p[0] | (p[1] << 8);
-        fg = a.swap ? px_swap16(v) : v;
-        m = p[2];
+        const uint8_t * p = reinterpret_cast<const uint8_t *>(base) + px * 3;
+#pragma unroll
+        for(int b = 0; b < 24; b++)
+            if(b / 3 >= j0 && b / 3 < j1) sw[b >> 2] |= (uint32_t)p[b] << ((b & 3) * 8);
     }
-    if(a.mask) m = a.mask[(long long)f * a.mask_fs + (size_t)y * a.mask_stride + x];
 }
 
 // How k_blend_rows maps lanes to groups (filled in by the launcher).
 struct RowsMap {
-    int uniform;           // 1: rows of all frames share one alignment
-    uint32_t k_lo, k_hi;   // whole groups of a row are k_lo .. k_hi-1
-    uint32_t n_whole_row;  // k_hi - k_lo
-    int edge_lo, edge_hi;  // group 0 / group k_hi is a partial group that holds pixels of the area
+    uint32_t groups_per_row;  // lanes per row of the area: the 16-byte groups a row overlaps (worst case when rows differ)
+    long long src_span;       // source pixels from the area's first to its last pixel, + 1: what a wide source load may touch
+    long long mask_span;      // the same for the mask, in bytes
 };
 
-// OM: the opacity mode fixed at compile time (the launcher picks it; OM_RUNTIME for the blend modes and anything
-// else) -- this kernel spends its time issuing integer instructions, not waiting for memory.
-template <int SRC, int OM>
-__global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, uint32_t gmax, RowsMap map)
+// Store the pixels of r whose bit is set in pm (bit j = pixel j of the 16-byte group at p), nothing else: 8-, 4- and
+// 2-byte pieces, so that a row's first and last group cost at most a handful of stores.
+__device__ __forceinline__ void store_group_masked(uint16_t * p, uint4 r, uint32_t pm)
 {
-    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    uint32_t y, k;
-    if(map.uniform) {
-        // every row of every frame starts at the same position within its 16-byte group, so the launcher knows which
-        // groups are whole: those come first (lanes that only ever take the vector path), the at most two partial
-        // groups per row come last, in wavefronts of their own
-        const uint32_t n_whole = map.n_whole_row * (uint32_t)a.h;
-        if(idx < n_whole) {
-            y = idx / map.n_whole_row;
-            k = map.k_lo + (idx - y * map.n_whole_row);
-        }
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for(int half = 0; half < 2; half++) {
+        const uint32_t hm = (pm >> (half * 4)) & 0xFu;
+        if(hm == 0xFu) *reinterpret_cast<uint2 *>(p + half * 4) = make_uint2(w[half * 2], w[half * 2 + 1]);
         else {
-            const uint32_t e = idx - n_whole;
-            y = e >> 1;
-            k = (e & 1u) ? map.k_hi : 0u;
-            if(y >= (uint32_t)a.h || !((e & 1u) ? map.edge_hi : map.edge_lo)) return;
+#pragma unroll
+            for(int q = 0; q < 2; q++) {
+                const uint32_t dm = (hm >> (q * 2)) & 3u;
+                const int px = half * 4 + q * 2;
+                if(dm == 3u) *reinterpret_cast<uint32_t *>(p + px) = w[half * 2 + q];
+                else if(dm == 1u) p[px] = (uint16_t)w[half * 2 + q];
+                else if(dm == 2u) p[px + 1] = (uint16_t)(w[half * 2 + q] >> 16);
+            }
         }
     }
-    else {
-        y = idx / gmax;
-        k = idx - y * gmax;
-        if(y >= (uint32_t)a.h) return;
-    }
+}
+
+// OM: the opacity mode fixed at compile time (the launcher picks it; OM_RUNTIME for the blend modes and anything
+// else).  Lanes are dealt to groups row by row, so a wavefront holds whole runs of consecutive groups of a few rows,
+// first and last group of each row included: the short stores that complete a row's first and last 128-byte line are
+// issued by the same wavefront, in the same few instructions, as the 16-byte stores to the rest of those lines, and
+// the lines reach memory once.  Every lane takes the same path: aligned 16-byte destination load (for a group that
+// sticks out of the area this reads up to 14 bytes beside the area, inside the same aligned 16-byte word), wide source
+// and mask loads, the vector blend, and a store of the area's pixels only.  A wide source or mask load that would
+// leave the rows that belong to the area (first group of the first row, last group of the last row) is replaced by
+// loads of the area's pixels alone.
+constexpr int ROWS_UNROLL = 1;  // groups per lane (all loaded before any is blended); 2 measured 2-5 % slower
+template <int SRC, int OM>
+__global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, RowsMap map)
+{
+    const uint32_t n_groups = map.groups_per_row * (uint32_t)a.h;
+    const uint32_t idx0 = blockIdx.x * (256 * ROWS_UNROLL) + threadIdx.x;
+    if(idx0 >= n_groups) return;
     for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
-        uint16_t * row = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride;
-        const int off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7u);  // row start within its 16-byte group
-        const int x_lo = (int)k * 8 - off;
-        if(x_lo >= a.w) continue;
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-        if(x_lo >= 0 && x_lo + 8 <= a.w) {
-            const uint4 d = *reinterpret_cast<const uint4 *>(row + x_lo);
-            uint32_t sw[SrcWords<SRC>::N];
-            uint2 mk = make_uint2(0, 0);
-            if(SRC != SRC_FILL)
-                load_src_unaligned<SRC>(a.src, (long long)f * a.src_fs + (long long)y * a.src_stride + x_lo, sw);
+        uint16_t * grp[ROWS_UNROLL];
+        uint32_t pm[ROWS_UNROLL], scan0[ROWS_UNROLL];
+        uint4 d[ROWS_UNROLL];
+        uint32_t sw[ROWS_UNROLL][SrcWords<SRC>::N];
+        uint2 mk[ROWS_UNROLL];
+#pragma unroll
+        for(int u = 0; u < ROWS_UNROLL; u++) {
+            const uint32_t idx = idx0 + (uint32_t)u * 256u;
+            pm[u] = 0;
+            mk[u] = make_uint2(0, 0);
+            if(idx >= n_groups) continue;
+            const uint32_t y = idx / map.groups_per_row, k = idx - y * map.groups_per_row;
+            uint16_t * row = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride;
+            const int off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7u);  // row start within its 16-byte group
+            const int x_lo = (int)k * 8 - off;
+            if(x_lo >= a.w) continue;
+            const int j0 = x_lo < 0 ? -x_lo : 0, j1 = a.w - x_lo < 8 ? a.w - x_lo : 8;  // pixels [j0, j1) are the area's
+            pm[u] = ((1u << j1) - 1u) & ~((1u << j0) - 1u);
+            grp[u] = row + x_lo;
+            scan0[u] = y * (uint32_t)a.w + (uint32_t)x_lo;
+            d[u] = *reinterpret_cast<const uint4 *>(grp[u]);
+            if(SRC != SRC_FILL) {
+                const long long so = (long long)y * a.src_stride + x_lo;
+                if(so >= 0 && so + 8 <= map.src_span) load_src_unaligned<SRC>(a.src, (long long)f * a.src_fs + so, sw[u]);
+                else load_src_guarded<SRC>(a.src, (long long)f * a.src_fs + so, j0, j1, sw[u]);
+            }
             if(a.mask) {
-                u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(a.mask + (long long)f * a.mask_fs + (size_t)y * a.mask_stride + x_lo);
-                mk = make_uint2(v.x, v.y);
-            }
-            *reinterpret_cast<uint4 *>(row + x_lo) =
-                blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d, sw, mk, y * (uint32_t)a.w + (uint32_t)x_lo, fnb);
-        }
-        else {
-            // A group that sticks out of the area on one side.  The aligned 16-byte word is read whole (it shares its
-            // page with the pixels that do belong to the area); source and mask are fetched pixel by pixel, for the
-            // area's pixels only and all of them before any arithmetic; only the area's pixels are written back.
-            const uint4 d = *reinterpret_cast<const uint4 *>(row + x_lo);
-            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
-            uint32_t fg[8], m[8];
+                const long long mo = (long long)y * a.mask_stride + x_lo;
+                const uint8_t * mp = a.mask + (long long)f * a.mask_fs + mo;
+                if(mo >= 0 && mo + 8 <= map.mask_span) {
+                    u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(mp);
+                    mk[u] = make_uint2(v.x, v.y);
+                }
+                else {
 #pragma unroll
-            for(int j = 0; j < 8; j++) {
-                const int x = x_lo + j;
-                fg[j] = a.color;
-                m[j] = 0;
-                if(x >= 0 && x < a.w) fetch_one_px<SRC>(a, f, (uint32_t)x, y, fg[j], m[j]);
-            }
-#pragma unroll
-            for(int j = 0; j < 8; j++) {
-                const int x = x_lo + j;
-                if(x >= 0 && x < a.w) {
-                    uint32_t dn = (dw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    if(a.swap) dn = px_swap16(dn);
-                    uint32_t r = px_core_s<OM, OM == OM_RUNTIME>(a, dn, fg[j], m[j], y * (uint32_t)a.w + (uint32_t)x, fnb);
-                    if(a.swap) r = px_swap16(r);
-                    row[x] = (uint16_t)r;
+                    for(int j = 0; j < 8; j++)
+                        if(j >= j0 && j < j1) {
+                            const uint32_t m = mp[j];
+                            if(j < 4) mk[u].x |= m << (j * 8);
+                            else mk[u].y |= m << ((j - 4) * 8);
+                        }
                 }
             }
+        }
+#pragma unroll
+        for(int u = 0; u < ROWS_UNROLL; u++) {
+            if(pm[u] == 0) continue;
+            const uint4 r = blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d[u], sw[u], mk[u], scan0[u], fnb);
+            if(pm[u] == 0xFFu) *reinterpret_cast<uint4 *>(grp[u]) = r;
+            else store_group_masked(grp[u], r, pm[u]);
         }
     }
 }
@@ -729,7 +775,11 @@ __device__ __forceinline__ void px_mix_with_alpha(uint32_t bg, uint32_t bg_opa, 
     }
     else {
         res_opa = 255u - (((255u - fg_opa) * (255u - bg_opa)) >> 8);
-        const uint32_t ratio = (fg_opa * 255u) / res_opa;
+        // (fg_opa * 255) / res_opa without the integer-division sequence: the quotient is below 256 and a quotient
+        // that is not whole lies at least 1/255 under the next integer, while the reciprocal's error moves the
+        // product by less than 1e-4, so adding 0.001 before truncating gives floor() for every operand pair
+        // (checked for all 256 x 256 pairs with the reciprocal off by up to two units in the last place)
+        const uint32_t ratio = (uint32_t)__builtin_fmaf((float)(fg_opa * 255u), __builtin_amdgcn_rcpf((float)res_opa), 0.001f);
         res = px_mix(fg, bg, ratio & 0xFFu);
     }
 }
@@ -866,72 +916,125 @@ __device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, const uin
     }
 }
 
-// ARGB8565 destination over areas that are contiguous in memory: 8 pixels (24 bytes of destination) per lane and
-// access, ARGB_UNROLL groups per lane in flight.  gpf = groups per frame.
-constexpr int ARGB_UNROLL = 2;
+// ARGB8565 destination over areas that are contiguous in memory.  A lane blends 16 pixels = 48 bytes of destination,
+// a wavefront 1024 pixels = 3072 bytes.  48-byte pieces do not make coalesced accesses (each of a lane's three
+// 16-byte words would sit 48 bytes from its neighbour's), so the wavefront moves its 3072 bytes as three fully
+// coalesced 1-KB instructions -- lane l takes 16-byte word i*64 + l -- and the words change owners through 3 KB of
+// wave-private LDS: word c of the run belongs to lane c / 3 (reads at a 48-byte lane stride are conflict-free: 3 is
+// odd).  The way back is the same in reverse.  gpf = 16-pixel groups per frame, cpf = blocks per frame.
+constexpr int ARGB_WAVE_GROUPS = 64;                    // 16-pixel groups per wavefront
+constexpr int ARGB_BLOCK_GROUPS = 4 * ARGB_WAVE_GROUPS; // per 256-thread block
 template <int SRC>
 __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t gpf, uint32_t cpf)
 {
+    __shared__ uint4 xch[4][3 * 64];
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t f = blk / cpf;
     const uint32_t c = blk - f * cpf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t * dst = reinterpret_cast<uint8_t *>(a.dst) + (long long)f * a.dst_fs * 3;
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
-    const uint32_t g0 = c * (256 * ARGB_UNROLL) + threadIdx.x;
-    uint32_t dw[ARGB_UNROLL][6];
-    uint2 mk[ARGB_UNROLL];
-    uint32_t sw[ARGB_UNROLL][SrcWords<SRC>::N];
+    const uint32_t gw = c * ARGB_BLOCK_GROUPS + (uint32_t)wave * ARGB_WAVE_GROUPS;  // the wavefront's first group
+    if(gw >= gpf) return;   // no block-wide barrier below: a wave may leave on its own
+    const uint32_t g = gw + (uint32_t)lane;                                          // this lane's group
+    const uint32_t n_words = gpf * 3u;                                               // 16-byte words per frame
+    uint4 * dst16 = reinterpret_cast<uint4 *>(dst);
     // without a per-pixel alpha and at full opacity colour and alpha are stored whatever the pixel held (:465-477, :768-790)
     const bool blended = SRC != SRC_FILL && a.raw_mode >= 1 && a.raw_mode <= 3;
     const bool need_dst = a.has_mask || a.raw_opa < 253 || blended;
+    uint32_t dw[2][6];
+    uint2 mk[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+    uint32_t sw[2][SrcWords<SRC>::N];
+    if(need_dst) {
+        uint4 v[3];
 #pragma unroll
-    for(int u = 0; u < ARGB_UNROLL; u++) {
-        const uint32_t g = g0 + u * 256;
-        mk[u] = make_uint2(0, 0);
+        for(int i = 0; i < 3; i++) {
+            const uint32_t word = gw * 3u + (uint32_t)(i * 64 + lane);
+            v[i] = word < n_words ? dst16[word] : make_uint4(0, 0, 0, 0);
+        }
         if(g < gpf) {
-            uint2 v0 = make_uint2(0, 0), v1 = v0, v2 = v0;
-            if(need_dst) {
-                const uint2 * p = reinterpret_cast<const uint2 *>(dst + (size_t)g * 24);
-                v0 = p[0];
-                v1 = p[1];
-                v2 = p[2];
+            if(SRC != SRC_FILL) {
+                load_src<SRC>(a.src, src_px0 + (long long)g * 16, sw[0]);
+                load_src<SRC>(a.src, src_px0 + (long long)g * 16 + 8, sw[1]);
             }
-            dw[u][0] = v0.x; dw[u][1] = v0.y; dw[u][2] = v1.x; dw[u][3] = v1.y; dw[u][4] = v2.x; dw[u][5] = v2.y;
-            if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)g * 8, sw[u]);
-            if(mask) mk[u] = *reinterpret_cast<const uint2 *>(mask + (size_t)g * 8);
+            if(mask) {
+                const uint4 m = *reinterpret_cast<const uint4 *>(mask + (size_t)g * 16);
+                mk[0] = make_uint2(m.x, m.y);
+                mk[1] = make_uint2(m.z, m.w);
+            }
+        }
+#pragma unroll
+        for(int i = 0; i < 3; i++) xch[wave][i * 64 + lane] = v[i];
+        wave_lds_fence();
+        const uint4 w0 = xch[wave][3 * lane], w1 = xch[wave][3 * lane + 1], w2 = xch[wave][3 * lane + 2];
+        dw[0][0] = w0.x; dw[0][1] = w0.y; dw[0][2] = w0.z; dw[0][3] = w0.w; dw[0][4] = w1.x; dw[0][5] = w1.y;
+        dw[1][0] = w1.z; dw[1][1] = w1.w; dw[1][2] = w2.x; dw[1][3] = w2.y; dw[1][4] = w2.z; dw[1][5] = w2.w;
+        wave_lds_fence();
+    }
+    else {
+#pragma unroll
+        for(int i = 0; i < 6; i++) dw[0][i] = dw[1][i] = 0;
+        if(g < gpf && SRC != SRC_FILL) {
+            load_src<SRC>(a.src, src_px0 + (long long)g * 16, sw[0]);
+            load_src<SRC>(a.src, src_px0 + (long long)g * 16 + 8, sw[1]);
         }
     }
+    if(g < gpf) {
+        argb_group<SRC>(a, dw[0], sw[0], mk[0], a.color);
+        argb_group<SRC>(a, dw[1], sw[1], mk[1], a.color);
+    }
+    xch[wave][3 * lane] = make_uint4(dw[0][0], dw[0][1], dw[0][2], dw[0][3]);
+    xch[wave][3 * lane + 1] = make_uint4(dw[0][4], dw[0][5], dw[1][0], dw[1][1]);
+    xch[wave][3 * lane + 2] = make_uint4(dw[1][2], dw[1][3], dw[1][4], dw[1][5]);
+    wave_lds_fence();
 #pragma unroll
-    for(int u = 0; u < ARGB_UNROLL; u++) {
-        const uint32_t g = g0 + u * 256;
-        if(g < gpf) {
-            argb_group<SRC>(a, dw[u], sw[u], mk[u], a.color);
-            uint2 * p = reinterpret_cast<uint2 *>(dst + (size_t)g * 24);
-            p[0] = make_uint2(dw[u][0], dw[u][1]);
-            p[1] = make_uint2(dw[u][2], dw[u][3]);
-            p[2] = make_uint2(dw[u][4], dw[u][5]);
-        }
+    for(int i = 0; i < 3; i++) {
+        const uint32_t word = gw * 3u + (uint32_t)(i * 64 + lane);
+        if(word < n_words) dst16[word] = xch[wave][i * 64 + lane];
     }
 }
 
-// Scan index of the first non-black destination pixel of the area, per frame (min-reduction, atomicMin).
+// Scan index of the first non-black destination pixel of the area, per frame.  Block (g, f) walks the g-th segment
+// of seg_px pixels of frame f in scan order, 1024 pixels at a time, and stops at the first piece that holds a
+// non-black pixel: for almost every frame that is the first piece of segment 0, so the pass reads a few KB per frame.
+// One atomicMin per block that found something (first_nb[] starts at 0xFFFFFFFF = "none").
 __global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, long long dst_fs, int dst_stride, int w, int h,
-                                                        int n_frames, uint32_t * first_nb)
+                                                        int n_frames, uint32_t seg_px, uint32_t * first_nb)
 {
+    __shared__ uint32_t wave_best[4];
     const uint32_t area = (uint32_t)w * (uint32_t)h;
+    const uint32_t lo = blockIdx.x * seg_px, hi = min(lo + seg_px, area);
+    const bool contiguous = dst_stride == w;
     for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y) {
-        uint32_t best = 0xFFFFFFFFu;
-        for(uint32_t idx = blockIdx.x * 256 + threadIdx.x; idx < area; idx += gridDim.x * 256) {
-            const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
-            if(dst[(long long)f * dst_fs + (size_t)y * dst_stride + x] != 0) {
-                best = idx;  // indices only grow along this loop
+        const uint16_t * frame = dst + (long long)f * dst_fs;
+        uint32_t found = 0xFFFFFFFFu;
+        for(uint32_t base = lo; base < hi; base += 1024u) {  // every thread of the block takes the same trips
+            uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+            for(int k = 3; k >= 0; k--) {  // descending, so that the smallest index is assigned last
+                const uint32_t idx = base + (uint32_t)k * 256u + threadIdx.x;
+                if(idx < hi) {
+                    size_t at = idx;
+                    if(!contiguous) {
+                        const uint32_t y = idx / (uint32_t)w;
+                        at = (size_t)y * dst_stride + (idx - y * (uint32_t)w);
+                    }
+                    if(frame[at] != 0) best = idx;
+                }
+            }
+#pragma unroll
+            for(int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
+            if((threadIdx.x & 63) == 0) wave_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            const uint32_t b = min(min(wave_best[0], wave_best[1]), min(wave_best[2], wave_best[3]));
+            __syncthreads();
+            if(b != 0xFFFFFFFFu) {
+                found = b;
                 break;
             }
         }
-#pragma unroll
-        for(int s = 32; s > 0; s >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, s, 64));
-        if((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(&first_nb[f], best);
+        if(threadIdx.x == 0 && found != 0xFFFFFFFFu) atomicMin(&first_nb[f], found);
     }
 }
 

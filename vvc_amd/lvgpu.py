@@ -147,6 +147,33 @@ def lv_draw_sw_blend(ctx, dsc, stream=None):
     check(_lib.lib().lvgpu_blend_batch(C.byref(b), _stream(stream)))
 
 
+class PreparedBlend:
+    """One lv_draw_sw_blend (optionally + flush) call marshalled once: run() is a single call into the C ABI, for
+    loops where the Python-side marshalling of lv_draw_sw_blend() would take longer than the kernel."""
+
+    def __init__(self, ctx, dsc, rotation=None, swap_bytes=0, out=None):
+        self._keep = (ctx, dsc, out)
+        self.out = out
+        if rotation is None:
+            self._b = _fill_batch(ctx, dsc)
+            self._fn = _lib.lib().lvgpu_blend_batch
+        else:
+            n, h, w = ctx.buf.shape
+            if out is None:
+                shape = (n, w, h) if rotation in (LV_DISP_ROT_90, LV_DISP_ROT_270) else (n, h, w)
+                self.out = out = torch.empty(shape, dtype=ctx.buf.dtype, device=ctx.buf.device)
+            bf = BlendFlushBatch()
+            bf.blend = _fill_batch(ctx, dsc)
+            bf.out, bf.out_frame_stride = out.data_ptr(), (out.stride(0) if n > 1 else h * w)
+            bf.rotation, bf.swap_bytes = rotation, int(swap_bytes)
+            self._b = bf
+            self._fn = _lib.lib().lvgpu_blend_flush_batch
+        self._ref = C.byref(self._b)
+
+    def run(self, stream=None):
+        check(self._fn(self._ref, _stream(stream)))
+
+
 def lv_draw_sw_blend_noalloc(ctx, dsc, stream=None):
     """lv_draw_sw_blend through lvgpu_blend_batch_noalloc: same result, no device allocation inside the call."""
     b = _fill_batch(ctx, dsc)
