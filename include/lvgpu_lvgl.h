@@ -143,8 +143,15 @@ void lvgpu_lvgl_set_color_16_swap(int swap);
  * draw_ctx->wait_for_finish itself is left NULL in this mode, because lv_draw_sw_blend calls it before every single
  * blend (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:103); all of LVGL's callers check the pointer.  A display
  * driver that keeps its own flush_cb must therefore call lvgpu_wait_for_finish(drv->draw_ctx) first thing in it.
- * Code that writes draw_ctx->buf directly between blends, other than through the hooks above, is not supported
- * in this mode.  A display with drv->sw_rotate set (LVGL rotates the draw buffer on the CPU right before flush_cb,
+ * Host code that reads or writes draw_ctx->buf directly between blends, other than through the hooks above, is not
+ * supported in this mode: it would see pixels that are still queued.  LVGL itself has one such reader, the sub-pixel
+ * text renderer (draw_letter_subpx reads the destination, libraries/lvgl/src/draw/sw/lv_draw_sw_letter.c:423), so
+ * the mode requires LV_USE_FONT_SUBPX 0 (the reference firmware's setting).  These two requirements -- a cooperating
+ * flush_cb and no direct readers -- are why the mode is opt-in.
+ * The draw buffer travels to the device only when no queued item overwrites all of it (a screen background does),
+ * and comes back once per submission; a refresh that queues exactly what the previous one queued (same rectangles,
+ * colours, opacities; mask and image bytes may differ) replays the plan made for the previous one instead of planning
+ * again (lvgpu_lvgl_stats_t.list_replays).  A display with drv->sw_rotate set (LVGL rotates the draw buffer on the CPU right before flush_cb,
  * libraries/lvgl/src/core/lv_refr.c:1262-1296, with no hook in between) stays in immediate mode.
  */
 void lvgpu_lvgl_set_deferred(int on);
@@ -192,7 +199,9 @@ int lvgpu_rotation_for_lvgl_sw_rotate(int lv_disp_rot);
  * lv_draw_sw_blend_basic (requests outside this library's coverage), flush calls, failed calls. */
 typedef struct {
     uint64_t blend_gpu, blend_delegated, flush_gpu, errors;
-    uint64_t blend_lists; /* deferred mode: display lists submitted */
+    uint64_t blend_lists;  /* deferred mode: display lists submitted */
+    uint64_t list_replays; /* ... of which drawn by replaying the plan of the previous, identical refresh */
+    uint64_t submit_ns;    /* host time spent submitting (copies, planning, launch, wait), nanoseconds */
 } lvgpu_lvgl_stats_t;
 void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out);
 void lvgpu_lvgl_reset_stats(void);

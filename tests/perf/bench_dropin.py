@@ -48,6 +48,9 @@ def main():
                                 None, None, 1, flags)
         R.ref_scene_build(scene)
         R.ref_scene_refresh()
+        R.ref_scene_build(scene)
+        R.ref_scene_refresh()            # deferred mode: the second identical refresh compiles the list
+        L.lvgpu_lvgl_reset_stats()
         t0 = time.perf_counter()
         for _ in range(reps):
             R.ref_scene_build(scene)   # invalidates the screen again
@@ -55,7 +58,10 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         fb = R.ref_scene_draw_buf() if mode.endswith("flush_cb") else R.ref_scene_fb()  # no capture with a foreign flush_cb
         frames[mode] = np.ctypeslib.as_array(C.cast(fb, C.POINTER(C.c_uint8)), shape=(H * W * bpp,)).copy()
-        print("%-22s %8.2f ms per refresh of scene %d (%dx%d, flags %d)" % (mode, dt * 1e3, scene, W, H, flags), flush=True)
+        st = (C.c_uint64 * 7)()
+        L.lvgpu_lvgl_get_stats(st)
+        print("%-22s %8.3f ms per refresh of scene %d (%dx%d, flags %d); of it submitting %.3f ms (%d lists, %d replayed)"
+              % (mode, dt * 1e3, scene, W, H, flags, st[6] / reps * 1e-6, st[4], st[5]), flush=True)
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
     R.ref_scene_set_pre_flush(None)
     print("identical frames:", all(np.array_equal(frames["lvgl_sw"], v) for v in frames.values()))

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 class Stats(C.Structure):
     _fields_ = [("blend_gpu", C.c_uint64), ("blend_delegated", C.c_uint64), ("flush_gpu", C.c_uint64),
-                ("errors", C.c_uint64), ("blend_lists", C.c_uint64)]
+                ("errors", C.c_uint64), ("blend_lists", C.c_uint64), ("list_replays", C.c_uint64), ("submit_ns", C.c_uint64)]
 
 
 class FlushCfg(C.Structure):
@@ -147,3 +147,49 @@ def test_widget_scene_with_lvgl_own_sw_rotate(world, lv_rot):
     L.lvgpu_lvgl_get_stats(C.byref(st))
     assert st.blend_gpu > 0 and st.blend_delegated == 0 and st.blend_lists == 0
     assert np.array_equal(got, sw), "%d pixels differ" % int((got != sw).sum())
+
+
+@pytest.mark.parametrize("flush", [0, 1])
+@pytest.mark.parametrize("flags", [0, 2])
+def test_repeated_refreshes_replay_the_plan(world, oracle, flush, flags, request):
+    """Deferred mode plans a refresh's display list once when the next refresh queues the same items, and replays that
+    plan from then on; a refresh with other content falls back to planning and the replay resumes afterwards.  Every
+    frame -- planned, compiled or replayed -- equals LVGL's own."""
+    swap, R, L = world
+    if not request.node.callspec.params["world"][1]:
+        pytest.skip("deferred mode only")
+    if flush and flags:
+        pytest.skip("the reference flushes lv_color_t buffers only")
+    w, h = 480, 320
+    sw = {sc: _render_sw(R, w, h, sc, flags) for sc in (1, 2)}
+    chunks = []
+
+    def sink(_user, xs, ys, xe, ye, data):
+        chunks.append(np.ctypeslib.as_array(data, shape=((xe - xs) * (ye - ys),)).copy())
+
+    cb = DRAW_BITMAP(sink)
+    cfg = FlushCfg(1, w * h // 10, 0, C.cast(cb, C.c_void_p), None, None)
+    L.lvgpu_lvgl_reset_stats()
+    assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                               _addr(L.lvgpu_flush_cb) if flush else None, C.addressof(cfg) if flush else None, 1, flags) == 0
+    st = Stats()
+    replays = []
+    for scene in (2, 2, 2, 2, 1, 2, 2, 2):
+        del chunks[:]
+        R.ref_scene_build(scene)
+        R.ref_scene_refresh()
+        if flush:
+            got = np.ctypeslib.as_array(C.cast(R.ref_scene_draw_buf(), C.POINTER(C.c_uint16)), shape=(h * w,))
+            assert np.array_equal(got, sw[scene])
+            panel = np.concatenate(chunks[-10:])
+            assert np.array_equal(panel, oracle.flush_frame(sw[scene], w, h, 1, 0))
+        else:
+            assert np.array_equal(_fb(R, w, h), sw[scene])
+        L.lvgpu_lvgl_get_stats(C.byref(st))
+        replays.append(int(st.list_replays))
+    assert st.errors == 0 and st.blend_delegated == 0
+    # refresh 1 plans, 2 compiles and replays, 3 and 4 replay; scene 1 plans; back on scene 2: plan, compile + replay, replay
+    assert replays[1] > replays[0] and replays[3] > replays[2] > replays[1]
+    assert replays[4] == replays[3] == replays[5] - 0 or replays[5] == replays[4]
+    assert replays[7] > replays[6] > replays[5]
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)

@@ -256,8 +256,7 @@ int dispatch_src(int fmt, Args &&... args)
 // off right above the tile kernel's value).  On a stream confined to some of the CUs (a CU mask) the same cap costs
 // 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied only to the
 // launches named at its uses, on streams that own the whole device.
-constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
-                   ARGB_PAD_LDS = 16 * 1024;  // (unused while the ARGB8565 kernel is being retuned)
+constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     static thread_local int dev_cached = -1, dev_cus = 0;
@@ -330,9 +329,8 @@ struct LaunchArgbLinear {
         const uint32_t cpf = (gpf + ARGB_BLOCK_GROUPS - 1) / ARGB_BLOCK_GROUPS;
         const uint64_t blocks = (uint64_t)cpf * a.n_frames;
         if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        uint32_t pad = 0;
-        if(getenv("LVGPU_DEV_ARGB_PAD")) pad = (uint32_t)atoi(getenv("LVGPU_DEV_ARGB_PAD"));
-        hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
+        // no residency cap: this kernel is bound by instruction issue (61 lane instructions per pixel), it only loses with one
+        hipLaunchKernelGGL(k_blend_argb_linear<SRC>, dim3((uint32_t)blocks), dim3(256), 0, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
@@ -345,7 +343,14 @@ struct LaunchStrip {
         const uint32_t strips_x = (W + TILE - 1) / TILE;
         const uint64_t n_strips = (uint64_t)strips_x * a.n_frames;
         if(n_strips > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        hipLaunchKernelGGL(k_strip<SRC>, dim3((uint32_t)((n_strips + 3) / 4)), dim3(256), 0, st, a, W, H, strips_x,
+        const int wpb = getenv("LVGPU_DEV_STRIP_WPB") ? atoi(getenv("LVGPU_DEV_STRIP_WPB")) : 4;
+        const uint32_t pad = getenv("LVGPU_DEV_STRIP_PAD") ? (uint32_t)atoi(getenv("LVGPU_DEV_STRIP_PAD")) : 0;
+        if(wpb == 1)
+            hipLaunchKernelGGL((k_strip<SRC, 1>), dim3((uint32_t)n_strips), dim3(64), pad, st, a, W, H, strips_x, (uint32_t)n_strips);
+        else if(wpb == 2)
+            hipLaunchKernelGGL((k_strip<SRC, 2>), dim3((uint32_t)((n_strips + 1) / 2)), dim3(128), pad, st, a, W, H, strips_x, (uint32_t)n_strips);
+        else
+        hipLaunchKernelGGL((k_strip<SRC, 4>), dim3((uint32_t)((n_strips + 3) / 4)), dim3(256), pad, st, a, W, H, strips_x,
                            (uint32_t)n_strips);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;

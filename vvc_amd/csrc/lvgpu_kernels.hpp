@@ -477,13 +477,13 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
 // after every step each row emits the one 128-byte line that has just become complete, so every store is a whole,
 // aligned line; only the first and last line of a panel row (shared with its neighbour rows) are partial.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SRC>
-__global__ __launch_bounds__(256) void k_strip(BlendArgs a, int W, int H, uint32_t strips_x, uint32_t n_strips)
+template <int SRC, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_strip(BlendArgs a, int W, int H, uint32_t strips_x, uint32_t n_strips)
 {
-    __shared__ uint4 ring[4][64 * 16];
+    __shared__ uint4 ring[WPB][64 * 16];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t ws = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
+    const uint32_t ws = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wave);
     if(ws >= n_strips) return;  // no block-wide barrier below: a wave may leave on its own
     const uint32_t f = ws / strips_x;
     const uint32_t sx = ws - f * strips_x;
@@ -758,30 +758,24 @@ __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, RowsMap map)
 // (:737-874) on top of set_px_argb (:378-402) / set_px_argb_blend (:404-446) and lv_color_mix_with_alpha
 // (lv_color.h:530-577).  One pixel per lane, byte accesses.
 // ---------------------------------------------------------------------------------------------------------------
+// lv_color_mix_with_alpha (lv_color.h:530-577) as one lv_color_mix whose ratio and resulting opacity are selected
+// among the reference's four cases: the foreground as it is (mixing at 255 returns it exactly), the background as it
+// is (mixing at 0), a plain mix over an opaque background, and the general case with its division.
 __device__ __forceinline__ void px_mix_with_alpha(uint32_t bg, uint32_t bg_opa, uint32_t fg, uint32_t fg_opa,
                                                   uint32_t & res, uint32_t & res_opa)
 {
-    if(fg_opa >= 253u || bg_opa <= 2u) {
-        res = fg;
-        res_opa = fg_opa;
-    }
-    else if(fg_opa <= 2u) {
-        res = bg;
-        res_opa = bg_opa;
-    }
-    else if(bg_opa >= 253u) {
-        res = px_mix(fg, bg, fg_opa);
-        res_opa = 255u;
-    }
-    else {
-        res_opa = 255u - (((255u - fg_opa) * (255u - bg_opa)) >> 8);
-        // (fg_opa * 255) / res_opa without the integer-division sequence: the quotient is below 256 and a quotient
-        // that is not whole lies at least 1/255 under the next integer, while the reciprocal's error moves the
-        // product by less than 1e-4, so adding 0.001 before truncating gives floor() for every operand pair
-        // (checked for all 256 x 256 pairs with the reciprocal off by up to two units in the last place)
-        const uint32_t ratio = (uint32_t)__builtin_fmaf((float)(fg_opa * 255u), __builtin_amdgcn_rcpf((float)res_opa), 0.001f);
-        res = px_mix(fg, bg, ratio & 0xFFu);
-    }
+    const bool take_fg = fg_opa >= 253u || bg_opa <= 2u;   // :537-541
+    const bool take_bg = fg_opa <= 2u;                      // :543-547
+    const bool bg_cover = bg_opa >= 253u;                   // :549-552
+    const uint32_t opa4 = 255u - (((255u - fg_opa) * (255u - bg_opa)) >> 8);   // :562
+    // (fg_opa * 255) / res_opa without the integer-division sequence: the quotient is below 256 and a quotient
+    // that is not whole lies at least 1/255 under the next integer, while the reciprocal's error moves the
+    // product by less than 1e-4, so adding 0.001 before truncating gives floor() for every operand pair
+    // (checked for all 256 x 256 pairs with the reciprocal off by up to two units in the last place)
+    const uint32_t ratio4 = (uint32_t)__builtin_fmaf((float)(fg_opa * 255u), __builtin_amdgcn_rcpf((float)opa4), 0.001f) & 0xFFu;
+    const uint32_t ratio = take_fg ? 255u : (take_bg ? 0u : (bg_cover ? fg_opa : ratio4));
+    res_opa = take_fg ? fg_opa : (take_bg ? bg_opa : (bg_cover ? 255u : opa4));
+    res = px_mix(fg, bg, ratio);
 }
 
 // One destination pixel of the ARGB8565 path.  a: anything with raw_opa, raw_mode, has_mask, swap.  fill: no source

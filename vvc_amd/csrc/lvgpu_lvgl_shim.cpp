@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,7 +31,7 @@ blend_fn g_sw_blend_basic = nullptr;
 flush_ready_fn g_flush_ready = nullptr;
 int g_swap = 1;
 int g_deferred = 0;
-std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0};
+std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0}, g_replays{0}, g_submit_ns{0};
 
 typedef void * (*layer_init_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
 typedef void (*layer_adjust_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
@@ -40,24 +41,59 @@ typedef void (*buffer_copy_fn)(lvgpu_lv_draw_ctx_t *, void *, int16_t, const lvg
                                const lvgpu_lv_area_t *);
 
 // One queued blend: the clipped rectangle and where its private copies of source and mask lie in the arena.
+// Compared bytewise between refreshes (every byte is initialised, padding included: see make_item).
 struct QItem {
     lvgpu_area_t area;
-    size_t src_off, mask_off;
-    bool has_src, has_mask;
+    uint64_t src_off, mask_off;
     uint16_t color;
-    uint8_t opa, mode;
+    uint8_t opa, mode, has_src, has_mask;
+    uint8_t pad[2];
 };
+
+// Growable pinned host memory: the sources and masks of the queued blends are copied straight into it, so the one
+// transfer to the device is a DMA from pinned memory.
+struct PinnedArena {
+    uint8_t * data = nullptr;
+    size_t size = 0, cap = 0;
+    uint8_t * grow_to(size_t new_size);  // keeps the contents; returns data
+    void release()
+    {
+        if(data) (void)hipHostFree(data);
+        data = nullptr;
+        size = cap = 0;
+    }
+};
+
 struct Queue {
     std::vector<QItem> items;
-    std::vector<uint8_t> arena;
+    PinnedArena arena;
     std::vector<lvgpu_blend_batch_t> batch;
     void * buf = nullptr;          // the host draw buffer the queued items draw into
     lvgpu_area_t buf_area{0, 0, 0, 0};
     bool transp = false;
+    bool covered = false;          // some queued item overwrites the whole buffer: its previous contents do not matter
     void * d_fb = nullptr;
     size_t fb_cap = 0;
     void * d_arena = nullptr;
     size_t arena_cap = 0;
+    // Host draw buffers registered with the runtime (hipHostRegister) so that they travel by DMA; LVGL has one or two
+    // per display plus its layers' buffers, which come and go: a small table, oldest entry replaced.
+    struct Reg {
+        void * p;
+        size_t bytes;
+    };
+    std::vector<Reg> regs;
+    // A refresh that queues exactly what the previous one queued (same rectangles, opacities, colours, arena layout --
+    // the usual case for a UI between two changes of its layout; the bytes of the masks and images may differ) is drawn
+    // by replaying the list planned for the previous one.
+    std::vector<QItem> prev_items;
+    void * prev_buf = nullptr;
+    lvgpu_area_t prev_area{0, 0, 0, 0};
+    bool prev_transp = false;
+    int prev_sig = -1;             // -1: nothing recorded; else 0 = no flush, 1 + rot * 2 + swap = fused flush
+    int prev_seen = 0;             // consecutive submits with this content
+    lvgpu_list_t * compiled = nullptr;
+    bool uncompilable = false;
     // the software implementations behind the hooks this library wraps
     layer_init_fn sw_layer_init = nullptr;
     layer_adjust_fn sw_layer_adjust = nullptr;
@@ -98,6 +134,51 @@ constexpr uint32_t MAGIC = 0x4C564750u;  // "LVGP"
 
 void * lookup(const char * name) { return dlsym(RTLD_DEFAULT, name); }
 
+uint8_t * PinnedArena::grow_to(size_t new_size)
+{
+    if(new_size > cap) {
+        size_t want = cap ? cap : (size_t)1 << 20;
+        while(want < new_size) want *= 2;
+        uint8_t * p = nullptr;
+        HIP_OR_DIE(hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault));
+        if(size) memcpy(p, data, size);
+        if(data) HIP_OR_DIE(hipHostFree(data));
+        data = p;
+        cap = want;
+    }
+    size = new_size;
+    return data;
+}
+
+// Is [p, p + bytes) registered with the runtime?  Registers it if not (a failure is not an error: the copy then goes
+// through the runtime's own staging).
+void ensure_registered(Queue * q, void * p, size_t bytes)
+{
+    for(const Queue::Reg & r : q->regs)
+        if(r.p == p && r.bytes >= bytes) return;
+    for(size_t i = 0; i < q->regs.size(); i++)
+        if(q->regs[i].p == p) {  // the same buffer with another size: register again
+            (void)hipHostUnregister(p);
+            q->regs.erase(q->regs.begin() + (long)i);
+            break;
+        }
+    if(q->regs.size() >= 8) {
+        (void)hipHostUnregister(q->regs.front().p);
+        q->regs.erase(q->regs.begin());
+    }
+    if(hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) q->regs.push_back(Queue::Reg{p, bytes});
+    else (void)hipGetLastError();
+}
+
+void drop_compiled(Queue * q)
+{
+    if(q->compiled) (void)lvgpu_list_destroy(q->compiled);
+    q->compiled = nullptr;
+    q->uncompilable = false;
+    q->prev_sig = -1;
+    q->prev_seen = 0;
+}
+
 void ensure_capacity(ShimCtx * s, size_t px)
 {
     if(px <= s->cap_px) return;
@@ -131,53 +212,97 @@ struct FlushReq {
     int rot, swap_bytes;
 };
 
-// Submit the queue: draw buffer to the device, the whole list in one call, draw buffer back.  With fr the same
-// launch also writes the rotated panel image (the tiles are flushed from on-chip memory) and it comes back too.
+// Submit the queue: draw buffer to the device (unless a queued item overwrites all of it), the whole list in one
+// launch, draw buffer back.  With fr the same launch also writes the rotated panel image (the tiles are flushed from
+// on-chip memory) and it comes back too.
 void submit(ShimCtx * s, const FlushReq * fr = nullptr)
 {
     Queue * q = s->q;
     if(q == nullptr || q->items.empty()) return;
+    const auto t_start = std::chrono::steady_clock::now();
     const int W = q->buf_area.x2 - q->buf_area.x1 + 1, H = q->buf_area.y2 - q->buf_area.y1 + 1;
     const size_t bpp = q->transp ? 3 : 2;
     const size_t fb_bytes = (size_t)W * H * bpp;
     if(fb_bytes > q->fb_cap) {
+        drop_compiled(q);
         if(q->d_fb) HIP_OR_DIE(hipFree(q->d_fb));
         HIP_OR_DIE(hipMalloc(&q->d_fb, fb_bytes));
         q->fb_cap = fb_bytes;
     }
-    if(q->arena.size() > q->arena_cap) {
+    if(q->arena.size > q->arena_cap) {
+        drop_compiled(q);
         if(q->d_arena) HIP_OR_DIE(hipFree(q->d_arena));
-        q->arena_cap = q->arena.size() * 2;
+        q->arena_cap = q->arena.size * 2;
         HIP_OR_DIE(hipMalloc(&q->d_arena, q->arena_cap));
     }
     hipStream_t st = s->stream;
-    HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
-    if(!q->arena.empty()) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data(), q->arena.size(), hipMemcpyHostToDevice, st));
-    q->batch.resize(q->items.size());
-    for(size_t i = 0; i < q->items.size(); i++) {
-        const QItem & it = q->items[i];
-        lvgpu_blend_batch_t & b = q->batch[i];
-        memset(&b, 0, sizeof(b));
-        b.dst = q->d_fb;
-        b.dst_frame_stride = (int64_t)W * H;
-        b.buf_area = q->buf_area;
-        b.clip_area = it.area;
-        b.blend_area = it.area;
-        b.mask_area = it.area;
-        b.src = it.has_src ? reinterpret_cast<uint8_t *>(q->d_arena) + it.src_off : nullptr;
-        b.src_format = it.has_src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
-        b.mask = it.has_mask ? reinterpret_cast<uint8_t *>(q->d_arena) + it.mask_off : nullptr;
-        b.mask_res = LVGPU_MASK_RES_CHANGED;
-        b.n_frames = 1;
-        b.color = it.color;
-        b.opa = it.opa;
-        b.blend_mode = it.mode;
-        b.color_16_swap = (uint8_t)g_swap;
-        b.dst_argb8565 = q->transp ? 1 : 0;
+    ensure_registered(q, q->buf, fb_bytes);
+    if(!q->covered) HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
+    if(q->arena.size) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data, q->arena.size, hipMemcpyHostToDevice, st));
+
+    // the same content as the previous submit?
+    const int sig = fr ? 1 + fr->rot * 2 + (fr->swap_bytes ? 1 : 0) : 0;
+    const bool same = q->prev_sig == sig && q->prev_buf == q->buf && q->prev_transp == q->transp &&
+                      memcmp(&q->prev_area, &q->buf_area, sizeof(lvgpu_area_t)) == 0 && q->prev_items.size() == q->items.size() &&
+                      memcmp(q->prev_items.data(), q->items.data(), q->items.size() * sizeof(QItem)) == 0;
+    if(!same) {
+        if(q->compiled) (void)lvgpu_list_destroy(q->compiled);
+        q->compiled = nullptr;
+        q->uncompilable = false;
+        q->prev_items = q->items;
+        q->prev_buf = q->buf;
+        q->prev_area = q->buf_area;
+        q->prev_transp = q->transp;
+        q->prev_sig = sig;
+        q->prev_seen = 1;
     }
-    const int rc = fr ? lvgpu_blend_list_flush_batch(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr->d_out,
-                                                     (int64_t)W * H, fr->rot, fr->swap_bytes, st)
-                      : lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
+    else if(q->prev_seen < 1000000) q->prev_seen++;
+
+    int rc = LVGPU_OK;
+    bool drawn = false;
+    if(same && q->compiled == nullptr && !q->uncompilable) q->batch.clear();  // marshalled below, then compiled
+    if(!(same && q->compiled)) {
+        q->batch.resize(q->items.size());
+        for(size_t i = 0; i < q->items.size(); i++) {
+            const QItem & it = q->items[i];
+            lvgpu_blend_batch_t & b = q->batch[i];
+            memset(&b, 0, sizeof(b));
+            b.dst = q->d_fb;
+            b.dst_frame_stride = (int64_t)W * H;
+            b.buf_area = q->buf_area;
+            b.clip_area = it.area;
+            b.blend_area = it.area;
+            b.mask_area = it.area;
+            b.src = it.has_src ? reinterpret_cast<uint8_t *>(q->d_arena) + it.src_off : nullptr;
+            b.src_format = it.has_src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
+            b.mask = it.has_mask ? reinterpret_cast<uint8_t *>(q->d_arena) + it.mask_off : nullptr;
+            b.mask_res = LVGPU_MASK_RES_CHANGED;
+            b.n_frames = 1;
+            b.color = it.color;
+            b.opa = it.opa;
+            b.blend_mode = it.mode;
+            b.color_16_swap = (uint8_t)g_swap;
+            b.dst_argb8565 = q->transp ? 1 : 0;
+        }
+        if(same && !q->uncompilable) {  // second refresh in a row with this content: plan it once and keep the plan
+            rc = lvgpu_list_create(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr ? 1 : 0, fr ? fr->rot : 0,
+                                   fr ? fr->swap_bytes : 0, &q->compiled);
+            if(rc != LVGPU_OK) {  // e.g. a shape the tile pass does not take: the uncompiled call below draws it
+                q->compiled = nullptr;
+                q->uncompilable = true;
+                rc = LVGPU_OK;
+            }
+        }
+    }
+    if(q->compiled) {
+        rc = lvgpu_list_replay(q->compiled, nullptr, 0, fr ? fr->d_out : nullptr, (int64_t)W * H, st);
+        drawn = rc == LVGPU_OK;
+        if(drawn) g_replays++;
+    }
+    if(!drawn && rc == LVGPU_OK)
+        rc = fr ? lvgpu_blend_list_flush_batch(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr->d_out, (int64_t)W * H,
+                                               fr->rot, fr->swap_bytes, st)
+                : lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
     if(rc != LVGPU_OK) {
         fprintf(stderr, "lvgpu: drawing the queued display list failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
         g_errors++;
@@ -187,8 +312,10 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
     if(fr) HIP_OR_DIE(hipMemcpyAsync(fr->panel, fr->d_out, fb_bytes, hipMemcpyDeviceToHost, st));
     HIP_OR_DIE(hipStreamSynchronize(st));
     q->items.clear();
-    q->arena.clear();
+    q->arena.size = 0;
+    q->covered = false;
     g_lists++;
+    g_submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count();
 }
 
 inline ShimCtx * shim_of(lvgpu_lv_draw_ctx_t * c)
@@ -296,6 +423,10 @@ void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw
     if(s->magic == MAGIC) {
         if(s->q) {
             submit(s);  // e.g. a canvas or snapshot drawn through a temporary context expects its pixels now
+            if(s->stream) (void)hipStreamSynchronize(s->stream);
+            if(s->q->compiled) (void)lvgpu_list_destroy(s->q->compiled);
+            for(const Queue::Reg & r : s->q->regs) (void)hipHostUnregister(r.p);
+            s->q->arena.release();
             if(s->q->d_fb) (void)hipFree(s->q->d_fb);
             if(s->q->d_arena) (void)hipFree(s->q->d_arena);
             delete s->q;
@@ -377,32 +508,37 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
         const bool transp = drv->screen_transp != 0;
         if(!q->items.empty() && (q->buf != draw_ctx->buf || memcmp(&q->buf_area, &ba, sizeof(ba)) != 0 || q->transp != transp))
             submit(s);  // the context was pointed at another buffer (layers do that)
+        if(q->items.empty()) q->covered = false;
         q->buf = draw_ctx->buf;
         q->buf_area = ba;
         q->transp = transp;
         QItem it;
+        memset(&it, 0, sizeof(it));  // padding too: items are compared bytewise between refreshes
         it.area = lvgpu_area_t{a.x1, a.y1, a.x2, a.y2};
         it.has_src = src != nullptr;
         it.has_mask = mask != nullptr;
-        it.src_off = it.mask_off = 0;
         it.color = dsc->color;
         it.opa = dsc->opa;
         it.mode = dsc->blend_mode;
         if(src) {
-            it.src_off = (q->arena.size() + 15) & ~(size_t)15;
-            q->arena.resize(it.src_off + px * 2);
-            for(int y = 0; y < h; y++)
-                memcpy(q->arena.data() + it.src_off + (size_t)y * w * 2, src + (size_t)y * src_stride, (size_t)w * 2);
+            it.src_off = (q->arena.size + 15) & ~(size_t)15;
+            uint8_t * base = q->arena.grow_to(it.src_off + px * 2);
+            for(int y = 0; y < h; y++) memcpy(base + it.src_off + (size_t)y * w * 2, src + (size_t)y * src_stride, (size_t)w * 2);
         }
         if(mask) {
-            it.mask_off = (q->arena.size() + 15) & ~(size_t)15;
-            q->arena.resize(it.mask_off + px);
+            it.mask_off = (q->arena.size + 15) & ~(size_t)15;
+            uint8_t * base = q->arena.grow_to(it.mask_off + px);
             if(transp && src == nullptr && dsc->opa >= 253)
-                memcpy(q->arena.data() + it.mask_off, mask, px);  // fill_argb's opaque masked loop: one run of w*h bytes
+                memcpy(base + it.mask_off, mask, px);  // fill_argb's opaque masked loop: one run of w*h bytes
             else
-                for(int y = 0; y < h; y++)
-                    memcpy(q->arena.data() + it.mask_off + (size_t)y * w, mask + (size_t)y * mask_stride, (size_t)w);
+                for(int y = 0; y < h; y++) memcpy(base + it.mask_off + (size_t)y * w, mask + (size_t)y * mask_stride, (size_t)w);
         }
+        // An item that replaces every pixel of the buffer whatever it held (fill_normal :254-259 / map_normal :655-660
+        // over the whole buffer; with a transparent screen fill_argb :465-477 / map_argb :768-790): what the buffer
+        // holds now never reaches the result, so it need not travel to the device.
+        if(mask == nullptr && dsc->opa >= 253 && (dsc->blend_mode == 0 || (transp && src == nullptr)) && a.x1 == ba.x1 && a.y1 == ba.y1 &&
+           a.x2 == ba.x2 && a.y2 == ba.y2)
+            q->covered = true;
         q->items.push_back(it);
         g_blend_gpu++;
         return;
@@ -568,6 +704,8 @@ void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out)
     out->flush_gpu = g_flush_gpu;
     out->errors = g_errors;
     out->blend_lists = g_lists;
+    out->list_replays = g_replays;
+    out->submit_ns = g_submit_ns;
 }
 void lvgpu_lvgl_reset_stats(void)
 {
@@ -576,6 +714,8 @@ void lvgpu_lvgl_reset_stats(void)
     g_flush_gpu = 0;
     g_errors = 0;
     g_lists = 0;
+    g_replays = 0;
+    g_submit_ns = 0;
 }
 
 }  // extern "C"
