@@ -213,7 +213,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * dsc, void * stream
  * multiple of 8 pixels -- 16 for an ARGB8565 destination --, unaligned dst) is run through the lvgpu_blend_batch
  * path in its place in the order.  items is host memory and may be released when the call returns.  The tables the
  * kernel walks are planned on the host at every call (about 0.2 ms for 1600 items; see lvgpu_list_create for lists
- * that repeat) and travel through a pinned staging buffer that each calling thread keeps for its lifetime.
+ * that repeat) and travel through a pinned staging buffer that each calling thread keeps and releases when it exits.
  */
 int lvgpu_blend_list_batch(const lvgpu_blend_batch_t * items, int32_t n_items, void * stream);
 
@@ -256,7 +256,9 @@ int lvgpu_blend_list_plan(const lvgpu_blend_batch_t * geom, const lvgpu_blend_ba
  * Only lists that the tile pass takes whole can be compiled (see lvgpu_blend_list_batch); otherwise
  * LVGPU_ERR_UNSUPPORTED, and the uncompiled entry points remain.  flush != 0: replay also writes the panel images.
  * lvgpu_list_replay: dst == NULL / n_frames == 0 keep what geom named; another dst must have the same geometry
- * (buf_area, frame stride) and 16-byte alignment.  out / out_frame_stride are used when the list was created with flush.
+ * (buf_area, frame stride) and 16-byte alignment.  More frames than were recorded are accepted only when every source
+ * and mask of the list is shared by all frames (frame stride 0); otherwise LVGPU_ERR_ARG, since frame n_frames - 1
+ * would read past the recorded buffers.  out / out_frame_stride are used when the list was created with flush.
  * A list belongs to the device that was current when it was created; replaying it with another device current is
  * LVGPU_ERR_ARG.
  * There is no counterpart in the reference, whose producers re-issue their descriptors on every refresh.

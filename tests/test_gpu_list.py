@@ -289,3 +289,32 @@ def test_compiled_list_replay(gpu, oracle):
     d7 = torch.zeros((2, 16, 20), dtype=torch.int16, device="cuda")
     with pytest.raises(gpu.LvgpuError):
         gpu.BlendList(gpu.DrawCtx(d7), [gpu.BlendDsc((0, 0, 19, 15), color=1)]).compile()
+
+
+def test_compiled_list_replay_frame_count(gpu, oracle):
+    """A compiled list whose items read per-frame sources or masks refuses a replay over more frames than were recorded
+    (frame n - 1 would read past those buffers); a list of shared inputs takes any number of frames."""
+    rng = np.random.default_rng(33)
+    W, H, N = 64, 64, 3
+    area = (0, 0, W - 1, H - 1)
+    d = to_dev(rng.integers(0, 65536, (N, H, W), dtype=np.uint16))
+    ctx = gpu.DrawCtx(d, color_16_swap=1)
+    per_frame = to_dev(rand_mask(rng, (N, H, W)))
+    shared = to_dev(rand_mask(rng, (H, W)))
+    big = to_dev(rng.integers(0, 65536, (N + 4, H, W), dtype=np.uint16))
+    bl = gpu.BlendList(ctx, [gpu.BlendDsc(area, color=0x1234, mask_buf=per_frame, opa=255)]).compile()
+    bl.replay()                                      # the recorded batch
+    bl.replay(buf=big[:2])                           # fewer frames
+    with pytest.raises(gpu.LvgpuError) as ei:
+        bl.replay(buf=big)                           # more frames than the per-frame mask holds
+    assert ei.value.code == -1 and "recorded for 3 frames" in str(ei.value)
+    bl.release()
+    bl = gpu.BlendList(ctx, [gpu.BlendDsc(area, color=0x1234, mask_buf=shared, opa=255)]).compile()
+    before = to_np(big, np.uint16).copy()
+    bl.replay(buf=big)
+    exp = before.copy()
+    m = to_np(shared, np.uint8)
+    for f in range(N + 4):
+        oracle.blend(exp[f], area, area, area, color=0x1234, mask=m, opa=255, swap=1)
+    assert np.array_equal(to_np(big, np.uint16), exp)
+    bl.release()

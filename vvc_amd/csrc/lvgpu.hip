@@ -620,6 +620,12 @@ struct ListStaging {
     hipEvent_t ev = nullptr;
     bool pending = false;
     int device = -1;  // the event belongs to the device that was current when it was created
+    ~ListStaging()    // at thread exit: wait for a copy that may still read the buffer, then give everything back
+    {
+        if(pending && ev) (void)hipEventSynchronize(ev);
+        if(ev) (void)hipEventDestroy(ev);
+        if(host) (void)hipHostFree(host);
+    }
     int acquire(size_t bytes, uint8_t ** out)
     {
         if(pending) {
@@ -998,6 +1004,7 @@ struct CompiledList {
     uint8_t * dev;   // the tables
     ListArgs a;      // everything but dst / n_frames / out / out_fs, which a replay may set
     bool argb, wide, flush;
+    bool per_frame_inputs;  // some item reads a source or mask that advances from frame to frame
     void * dst;      // as recorded
     int n_frames;
 };
@@ -1249,6 +1256,7 @@ int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_
     cl->flush = flush != 0;
     cl->dst = geom->dst;
     cl->n_frames = geom->n_frames;
+    for(const ListItem & it : lb.items) cl->per_frame_inputs = cl->per_frame_inputs || it.src_fs != 0 || it.mask_fs != 0;
     *out_list = reinterpret_cast<lvgpu_list_t *>(cl);
     return LVGPU_OK;
 }
@@ -1265,6 +1273,9 @@ int lvgpu_list_replay(const lvgpu_list_t * list, void * dst, int32_t n_frames, v
     ListArgs a = cl->a;
     a.dst = reinterpret_cast<uint16_t *>(dst ? dst : cl->dst);
     a.n_frames = (uint32_t)(n_frames ? n_frames : cl->n_frames);
+    if(cl->per_frame_inputs && a.n_frames > (uint32_t)cl->n_frames)
+        return fail(LVGPU_ERR_ARG, "the list reads per-frame sources or masks recorded for %d frames; %u frames would read past them",
+                    cl->n_frames, a.n_frames);
     if(!aligned(a.dst, 16)) return fail(LVGPU_ERR_ARG, "dst must be 16-byte aligned");
     if(cl->flush) {
         if(out == nullptr) return fail(LVGPU_ERR_ARG, "out is NULL");

@@ -620,11 +620,18 @@ void lvgpu_flush_cb(lvgpu_lv_disp_drv_t * drv, const lvgpu_lv_area_t * area, lvg
 
     // rotate the whole area on the device (staging buffers are kept between calls and grown on demand)
     const size_t px = (size_t)W * H;
-    static thread_local struct {
+    struct FlushStaging {
         void *d_in = nullptr, *d_out = nullptr;
         uint16_t * panel = nullptr;
         size_t cap = 0;
-    } stg;
+        ~FlushStaging()  // at thread exit (every use is synchronous, nothing can still be in flight)
+        {
+            if(d_in) (void)hipFree(d_in);
+            if(d_out) (void)hipFree(d_out);
+            if(panel) (void)hipHostFree(panel);
+        }
+    };
+    static thread_local FlushStaging stg;
     if(px > stg.cap) {
         if(stg.d_in) HIP_OR_DIE(hipFree(stg.d_in));
         if(stg.d_out) HIP_OR_DIE(hipFree(stg.d_out));
