@@ -883,31 +883,106 @@ __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
     }
 }
 
+// How the effective opacity of a pixel of the ARGB8565 path comes about, decided once per launch or list item.
+// AM_GENERIC: the blend modes (set_px_argb_blend) and the plain store of an opaque unmasked fill, pixel by pixel
+// through argb_dst_px; the others are set_px_argb with o = opa / the mask / the two mask-times-opa forms.
+enum ArgbMode : int { AM_GENERIC = 0, AM_CONST = 1, AM_MASK = 2, AM_FILL_MASK_OPA = 3, AM_MAP_MASK_OPA = 4 };
+template <class A>
+__device__ __forceinline__ int argb_mode(const A & a, bool fill)
+{
+    const uint32_t opa = (uint32_t)a.raw_opa;
+    if(!fill && a.raw_mode >= 1 && a.raw_mode <= 3) return AM_GENERIC;
+    if(!a.has_mask) return (fill && opa >= 253u) ? AM_GENERIC : AM_CONST;
+    if(fill) return opa >= 253u ? AM_MASK : AM_FILL_MASK_OPA;
+    return opa > 253u ? AM_MASK : AM_MAP_MASK_OPA;
+}
+
 // Eight ARGB8565 destination pixels held as six dwords (24 bytes): pixel j occupies bytes 3j..3j+2.
+template <class T>
+__device__ __forceinline__ void argb_unpack8(const uint32_t * dw, T * v)  // v[j]: 24 bits of pixel j (+ garbage above)
+{
+    v[0] = dw[0];
+    v[1] = __builtin_amdgcn_alignbit(dw[1], dw[0], 24);
+    v[2] = __builtin_amdgcn_alignbit(dw[2], dw[1], 16);
+    v[3] = dw[2] >> 8;
+    v[4] = dw[3];
+    v[5] = __builtin_amdgcn_alignbit(dw[4], dw[3], 24);
+    v[6] = __builtin_amdgcn_alignbit(dw[5], dw[4], 16);
+    v[7] = dw[5] >> 8;
+}
+__device__ __forceinline__ void argb_pack8(const uint32_t * nv, uint32_t * dw)  // nv[j] < 2^24
+{
+    dw[0] = nv[0] | (nv[1] << 24);
+    dw[1] = (nv[1] >> 8) | (nv[2] << 16);
+    dw[2] = (nv[2] >> 16) | (nv[3] << 8);
+    dw[3] = nv[4] | (nv[5] << 24);
+    dw[4] = (nv[5] >> 8) | (nv[6] << 16);
+    dw[5] = (nv[6] >> 16) | (nv[7] << 8);
+}
+
+// set_px_argb (lv_draw_sw_blend.c:378-402) over the group for the normal blend mode, opacity per AM: no branches,
+// every pixel independent of its neighbours (the kernels that use this are bound by instruction issue).
+template <int SRC, int AM, class A>
+__device__ __forceinline__ void argb_group_normal(const A & a, uint32_t * dw, const uint32_t * sw, uint2 mk, uint32_t color)
+{
+    const uint32_t opa = (uint32_t)a.raw_opa;
+    const uint32_t sel16 = a.swap ? 0x0C0C0001u : 0x0C0C0100u;  // low 16 bits, bytes exchanged for a swapped build
+    uint32_t v[8], nv[8];
+    argb_unpack8(dw, v);
+#pragma unroll
+    for(int j = 0; j < 8; j++) {
+        uint32_t fg = color;
+        uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
+        src_px<SRC>(sw, j, a.swap, fg, m);
+        uint32_t o;
+        bool skip = false;
+        if(AM == AM_CONST) o = SRC == SRC_FILL ? opa : (opa >= 253u ? 255u : opa);       // :480-488 / :768-819
+        else if(AM == AM_MASK) o = m;                                                     // :494-505 / :824-843
+        else if(AM == AM_FILL_MASK_OPA) {                                                 // :507-528
+            skip = m == 0u;
+            o = m == 255u ? opa : (m * opa) >> 8;
+        }
+        else {                                                                            // :846-871
+            skip = m == 0u;
+            o = m >= 253u ? opa : (opa * m) >> 8;
+        }
+        const uint32_t bg = __builtin_amdgcn_perm(0u, v[j], sel16);
+        const uint32_t bg_opa = (v[j] >> 16) & 0xFFu;
+        uint32_t res, res_opa;
+        px_mix_with_alpha(bg, bg_opa, fg, o, res, res_opa);
+        const uint32_t c = res_opa > 2u ? __builtin_amdgcn_perm(0u, res, sel16) : (v[j] & 0xFFFFu);  // :391
+        const uint32_t n = c | (res_opa << 16);
+        nv[j] = skip ? (v[j] & 0xFFFFFFu) : n;
+    }
+    argb_pack8(nv, dw);
+}
+
 template <int SRC, class A>
 __device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, const uint32_t * sw, uint2 mk, uint32_t color)
 {
     constexpr bool fill = SRC == SRC_FILL;
+    switch(argb_mode(a, fill)) {  // the same for every pixel of a launch / list item
+        case AM_CONST: argb_group_normal<SRC, AM_CONST>(a, dw, sw, mk, color); return;
+        case AM_MASK: argb_group_normal<SRC, AM_MASK>(a, dw, sw, mk, color); return;
+        case AM_FILL_MASK_OPA: argb_group_normal<SRC, AM_FILL_MASK_OPA>(a, dw, sw, mk, color); return;
+        case AM_MAP_MASK_OPA: argb_group_normal<SRC, AM_MAP_MASK_OPA>(a, dw, sw, mk, color); return;
+        default: break;
+    }
+    uint32_t v[8], nv[8];
+    argb_unpack8(dw, v);
 #pragma unroll
     for(int j = 0; j < 8; j++) {
-        const int byte = 3 * j, w0 = byte >> 2, sh = (byte & 3) * 8;
-        const uint64_t two = (uint64_t)dw[w0] | ((uint64_t)dw[w0 + 1 < 6 ? w0 + 1 : 5] << 32);
-        const uint32_t v = (uint32_t)(two >> sh);
-        uint32_t bg = v & 0xFFFFu;
+        uint32_t bg = v[j] & 0xFFFFu;
         if(a.swap) bg = px_swap16(bg);
-        const uint32_t bg_opa = (v >> 16) & 0xFFu;
+        const uint32_t bg_opa = (v[j] >> 16) & 0xFFu;
         uint32_t fg = color;
         uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
         src_px<SRC>(sw, j, a.swap, fg, m);
         const ArgbOut r = argb_dst_px(a, fill, fg, m, bg, bg_opa);
-        uint32_t c = a.swap ? px_swap16(r.color) : r.color;
-        uint32_t nv = (r.wc ? c : (v & 0xFFFFu)) | ((r.wo ? r.opa : bg_opa) << 16);
-        // put the 24 bits back (they may straddle two dwords)
-        const uint64_t keep = ~((uint64_t)0xFFFFFFu << sh);
-        const uint64_t upd = (two & keep) | ((uint64_t)(nv & 0xFFFFFFu) << sh);
-        dw[w0] = (uint32_t)upd;
-        if(sh > 8) dw[w0 + 1 < 6 ? w0 + 1 : 5] = (uint32_t)(upd >> 32);
+        const uint32_t c = a.swap ? px_swap16(r.color) : r.color;
+        nv[j] = (r.wc ? c : (v[j] & 0xFFFFu)) | ((r.wo ? r.opa : bg_opa) << 16);
     }
+    argb_pack8(nv, dw);
 }
 
 // ARGB8565 destination over areas that are contiguous in memory.  A lane blends 16 pixels = 48 bytes of destination,
