@@ -9,7 +9,9 @@
  * asynchronous with respect to the host unless stated otherwise.  Entry points may be called from several host
  * threads as long as each thread uses its own device/stream.  The full-frame kernels look at the stream's CU mask
  * (hipExtStreamGetCUMask): on a stream that owns the whole device they cap how many workgroups share a CU, which
- * raises the HBM rate; a stream confined to some CUs keeps the default.  Results do not depend on it.
+ * raises the HBM rate; a stream confined to some CUs keeps the default.  Results do not depend on it.  The cap is a
+ * tuning measured on MI355X under ROCm 7.2; setting LVGPU_NO_RESIDENCY_CAP in the environment (read once, at the first
+ * launch) disables it, and tools/check_residency.py compares both settings on the machine at hand.
  *
  * Pixel vocabulary (libraries/lvgl/src/misc/lv_color.h:208-222): a pixel is lv_color16_t, 2 bytes.
  *   color_16_swap = 1 : LV_COLOR_16_SWAP 1, memory bytes {RRRRRGGG, GGGBBBBB} (big-endian RGB565 = panel wire order)
