@@ -18,7 +18,7 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     frames = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
     out = gpu.flush_rotate(to_dev(frames), rot, swap_bytes=swap_bytes)
     fast = W % 8 == 0 and H % 8 == 0
-    quarter = ("k_strip" if H % 32 else "k_tile")  # heights off the 32-px grid take the column-strip kernel
+    quarter = ("k_tile_col" if H % 32 else "k_tile")  # heights off the 32-px grid: a column of tiles per workgroup
     if rot in (1, 3):
         assert gpu.last_kernel() == (quarter if fast else "k_rotate_tile_any")  # the latter: sizes off the 8-pixel grid
     else:  # a copy / reversal only needs the frame to be a whole number of 8-pixel groups
@@ -113,7 +113,7 @@ def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
         dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
                            mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
         out = gpu.blend_flush(gpu.DrawCtx(d), dsc, rot)
-        assert gpu.last_kernel() == "k_strip(fused)"
+        assert gpu.last_kernel() == "k_tile_col(fused)"
         assert np.array_equal(to_np(d, np.uint16), exp_dst)
         got = to_np(out, np.uint16).reshape(N, -1)
         for f in range(N):

@@ -107,7 +107,7 @@ def test_config5_large_canvas_3840x2160(gpu, oracle):
     gpu.lv_draw_sw_blend(gpu.DrawCtx(d2), gpu.BlendDsc(area, src_buf=src, src_format=gpu.SRC_ARGB8888))
     out = gpu.blend_flush(gpu.DrawCtx(dst), gpu.BlendDsc(area, src_buf=src, src_format=gpu.SRC_ARGB8888),
                           gpu.LV_DISP_ROT_90)
-    assert gpu.last_kernel() == "k_strip(fused)"  # 2160 is not a multiple of 32
+    assert gpu.last_kernel() == "k_tile_col(fused)"  # 2160 is not a multiple of 32
     assert torch.equal(dst, d2)
     assert torch.equal(out, dst.flip(1).transpose(1, 2))
     assert torch.equal(gpu.flush_rotate(dst, gpu.LV_DISP_ROT_270), dst.flip(2).transpose(1, 2))

@@ -341,29 +341,21 @@ struct LaunchArgbLinear {
     }
 };
 template <int SRC>
-struct LaunchStrip {
+struct LaunchTileCol {
     static int run(const BlendArgs & a, hipStream_t st)
     {
         const int W = a.w, H = a.h;
-        const uint32_t strips_x = (W + TILE - 1) / TILE;
-        const uint64_t n_strips = (uint64_t)strips_x * a.n_frames;
-        if(n_strips > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const int wpb = getenv("LVGPU_DEV_STRIP_WPB") ? atoi(getenv("LVGPU_DEV_STRIP_WPB")) : 4;
-        const uint32_t pad = getenv("LVGPU_DEV_STRIP_PAD") ? (uint32_t)atoi(getenv("LVGPU_DEV_STRIP_PAD")) : 0;
-        if(wpb == 1)
-            hipLaunchKernelGGL((k_strip<SRC, 1>), dim3((uint32_t)n_strips), dim3(64), pad, st, a, W, H, strips_x, (uint32_t)n_strips);
-        else if(wpb == 2)
-            hipLaunchKernelGGL((k_strip<SRC, 2>), dim3((uint32_t)((n_strips + 1) / 2)), dim3(128), pad, st, a, W, H, strips_x, (uint32_t)n_strips);
-        else
-        hipLaunchKernelGGL((k_strip<SRC, 4>), dim3((uint32_t)((n_strips + 3) / 4)), dim3(256), pad, st, a, W, H, strips_x,
-                           (uint32_t)n_strips);
+        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * COL_WPB - 1) / (TILE * COL_WPB);
+        const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
+        if(n_blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_tile_col<SRC>, dim3((uint32_t)n_blocks), dim3(64 * COL_WPB), 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
 };
 // Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
-// the tile kernel's output runs degrade; the strip kernel writes whole lines regardless.
-inline bool wants_strip(const BlendArgs & a) { return (a.h % 32) != 0; }
+// the tile kernel's 128-byte output runs degrade; the column kernel writes 1-KB runs.
+inline bool wants_col(const BlendArgs & a) { return (a.h % 32) != 0; }
 
 template <int SRC>
 struct LaunchRows {
@@ -490,9 +482,9 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
     const bool out_ok = aligned(out, 16) && (out_fs % 8) == 0;
     const bool transposing = rot == LVGPU_ROT_90 || rot == LVGPU_ROT_270;
     if(out_ok && transposing && tile_ok(a, SRC_COPY)) {
-        if(wants_strip(a)) {
-            g_last_kernel = "k_strip";
-            return LaunchStrip<SRC_COPY>::run(a, st);
+        if(wants_col(a)) {
+            g_last_kernel = "k_tile_col";
+            return LaunchTileCol<SRC_COPY>::run(a, st);
         }
         g_last_kernel = "k_tile";
         return LaunchTile<SRC_COPY>::run(a, st);
@@ -1143,9 +1135,9 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
             uint32_t * owned = nullptr;
             int rc = prepare_first_nb(a, st, &owned);
             if(rc != LVGPU_OK) return rc;
-            if(transposing && wants_strip(a)) {
-                g_last_kernel = "k_strip(fused)";
-                rc = dispatch_src<LaunchStrip>(b.src_format, a, st);
+            if(transposing && wants_col(a)) {
+                g_last_kernel = "k_tile_col(fused)";
+                rc = dispatch_src<LaunchTileCol>(b.src_format, a, st);
             }
             else if(transposing) {
                 g_last_kernel = "k_tile(fused)";

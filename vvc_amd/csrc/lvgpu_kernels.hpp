@@ -469,43 +469,42 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_strip: the 90/270-degree path for frames whose height is not a multiple of 32 pixels.  There the panel rows
-// (2*H bytes each) start on 16/32/48-byte boundaries, a tile's 128-byte output runs fall apart into pieces smaller
-// than 64 bytes, and such pieces are written at a fraction of the full-line rate.  Here a wave owns a whole column
-// strip (64 columns x H rows) and walks it in 64-row steps in the direction of ascending panel addresses.  The
-// transposed 8-pixel chunks go into a 16-slot ring per panel row in LDS (slot = absolute chunk index mod 16), and
-// after every step each row emits the one 128-byte line that has just become complete, so every store is a whole,
-// aligned line; only the first and last line of a panel row (shared with its neighbour rows) are partial.
+// k_tile_col: k_tile for frames whose height is not a multiple of 32 pixels.  There the panel rows (2*H bytes each)
+// start on 32/64/96-byte offsets within a 128-byte line, a single tile's 128-byte output runs fall apart into two
+// pieces, and pieces below 64 bytes are written at a fraction of the full-line rate.  Here the COL_WPB wavefronts of a
+// workgroup take vertically adjacent tiles (64 columns x 64*COL_WPB rows), exchange their transposed blocks through
+// the workgroup's LDS, and every wavefront then writes whole panel-row runs of 128*COL_WPB bytes, one run per store
+// instruction (64 lanes x 16 bytes): only the first and the last line of a run are partial.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SRC, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void k_strip(BlendArgs a, int W, int H, uint32_t strips_x, uint32_t n_strips)
+constexpr int COL_WPB = 8;  // 5 to 7 (fewer empty tile slots on 4K, 1080p) and 16 measured slower: the run length counts
+template <int SRC>
+__global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, uint32_t n_blocks)
 {
-    __shared__ uint4 ring[WPB][64 * 16];
+    __shared__ uint4 lds[64 * 8 * COL_WPB];   // [panel row of the block 0..63][chunk of the run 0..8*COL_WPB-1], swizzled
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t ws = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wave);
-    if(ws >= n_strips) return;  // no block-wide barrier below: a wave may leave on its own
-    const uint32_t f = ws / strips_x;
-    const uint32_t sx = ws - f * strips_x;
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);  // gridDim.x == n_blocks
+    const uint32_t bpf = tiles_x * cols_y;
+    const uint32_t f = blk / bpf;
+    const uint32_t t = blk - f * bpf;
+    const uint32_t cy = t / tiles_x, tx = t - cy * tiles_x;   // neighbours in x follow each other: whole source rows stream
     constexpr bool BLEND = SRC != SRC_COPY;
+    constexpr int RUN = 8 * COL_WPB;                           // 16-byte chunks per output run
     const bool r90 = a.rot == 1;
-    const int hc = H >> 3;                       // chunks (8 px) per panel row
-    const int n_it = (H + TILE - 1) / TILE;
-    const int bx = lane & 7, by = lane >> 3;
-    const int x0 = sx * TILE + bx * 8;
-    uint16_t * dst = a.dst + (long long)f * a.dst_fs;
-    const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
-    const long long src_px0 = (long long)f * a.src_fs;
-    const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-    const int fast = fast_path<SRC>(a);
-    uint16_t * out = a.out + (long long)f * a.out_fs;
 
-    uint4 d[8];
-    uint2 mk[8];
-    uint32_t sw[8][SrcWords<SRC>::N];
-    // rows of step `it`: rot90 walks from the bottom of the frame up, rot270 from the top down
-    auto first_row = [&](int it) { return (r90 ? H - TILE * (it + 1) : TILE * it) + by * 8; };
-    auto fetch = [&](int y0) {
+    const int bx = lane & 7, by = lane >> 3;
+    const int Y0 = (int)cy * TILE * COL_WPB;                   // first source row of the block
+    const int x0 = tx * TILE + bx * 8, y0 = Y0 + wave * TILE + by * 8;
+    const bool inside = x0 < W && y0 < H;                      // H % 8 == 0: a lane's 8 rows are inside or outside together
+    if(inside) {
+        uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+        const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+        const long long src_px0 = (long long)f * a.src_fs;
+        const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+        const int fast = fast_path<SRC>(a);
+        uint4 d[8], r[8];
+        uint2 mk[8];
+        uint32_t sw[8][SrcWords<SRC>::N];
 #pragma unroll
         for(int i = 0; i < 8; i++) {
             const size_t p = (size_t)(y0 + i) * W + x0;
@@ -516,80 +515,48 @@ __global__ __launch_bounds__(64 * WPB) void k_strip(BlendArgs a, int W, int H, u
                 if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
             }
         }
-    };
-    int y0 = first_row(0);
-    bool inside = x0 < W && y0 >= 0 && y0 + 8 <= H;
-    if(inside) fetch(y0);
-
-    for(int it = 0; it < n_it; it++) {
-        uint4 r[8];
-        if(inside) {
 #pragma unroll
-            for(int i = 0; i < 8; i++) {
-                r[i] = d[i];
-                if(BLEND) {
-                    const size_t p = (size_t)(y0 + i) * W + x0;
-                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
-                    *reinterpret_cast<uint4 *>(dst + p) = r[i];
-                }
-                if(a.swap_out) r[i] = swap_group(r[i]);
+        for(int i = 0; i < 8; i++) {
+            r[i] = d[i];
+            if(BLEND) {
+                const size_t p = (size_t)(y0 + i) * W + x0;
+                r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                *reinterpret_cast<uint4 *>(dst + p) = r[i];
             }
+            if(a.swap_out) r[i] = swap_group(r[i]);
         }
-        // the next step's rows are requested now, so that they travel while this step is exchanged and written out
-        const int y0_next = first_row(it + 1);
-        const bool inside_next = it + 1 < n_it && x0 < W && y0_next >= 0 && y0_next + 8 <= H;
-        if(inside_next) fetch(y0_next);
-        if(inside) {
-            const int pc = 8 * it + (r90 ? 7 - by : by);   // chunk position inside the panel row
+        // position of this lane's 8 rows in the run, in ascending panel address order
+        const int c = r90 ? RUN - 1 - (wave * 8 + by) : wave * 8 + by;
 #pragma unroll
-            for(int j = 0; j < 8; j++) {
-                uint32_t o[4];
+        for(int j = 0; j < 8; j++) {
+            uint32_t o[4];
 #pragma unroll
-                for(int m = 0; m < 4; m++) {
-                    auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
-                    const uint32_t lo = r90 ? word(r[7 - 2 * m]) : word(r[2 * m]);
-                    const uint32_t hi = r90 ? word(r[6 - 2 * m]) : word(r[2 * m + 1]);
-                    o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-                }
-                const int xl = bx * 8 + j;
-                const int R = r90 ? x0 + j : W - 1 - (x0 + j);
-                const uint32_t ac = (uint32_t)R * (uint32_t)hc + (uint32_t)pc;   // absolute chunk index in the panel image
-                ring[wave][xl * 16 + ((ac ^ (uint32_t)bx) & 15u)] = make_uint4(o[0], o[1], o[2], o[3]);
+            for(int m = 0; m < 4; m++) {
+                auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
+                const uint32_t lo = r90 ? word(r[7 - 2 * m]) : word(r[2 * m]);
+                const uint32_t hi = r90 ? word(r[6 - 2 * m]) : word(r[2 * m + 1]);
+                o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
             }
+            const int xl = bx * 8 + j;
+            lds[xl * RUN + (c ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        wave_lds_fence();
-        {
-            const int rr = lane >> 3, c = lane & 7;
+    }
+    __syncthreads();
+    if(a.out) {
+        uint16_t * out = a.out + (long long)f * a.out_fs;
+        // first pixel of the run within its panel row; negative for the last block of a column, whose run sticks out
+        const int run0 = r90 ? H - Y0 - TILE * COL_WPB : Y0;
 #pragma unroll
-            for(int k = 0; k < 8; k++) {
-                const int xl = k * 8 + rr;
-                const int X = sx * TILE + xl;
-                if(X >= W) continue;
+        for(int k = 0; k < (64 * RUN) / (64 * COL_WPB); k++) {   // rows per wavefront: 64 rows x RUN chunks over all lanes
+            const int q = (k * COL_WPB + wave) * 64 + lane;      // chunk number within the block's 64 x RUN output
+            const int xl = q / RUN;
+            const int X = tx * TILE + xl;
+            const int px = run0 + (q - xl * RUN) * 8;
+            if(X < W && px >= 0 && px + 8 <= H) {
                 const int R = r90 ? X : W - 1 - X;
-                const uint32_t S = (uint32_t)R * (uint32_t)hc;                    // first chunk of this panel row
-                const uint32_t e_prev = S + (uint32_t)min(8 * it, hc);
-                const uint32_t e_now = S + (uint32_t)min(8 * (it + 1), hc);
-                const uint32_t sw_x = (uint32_t)(xl >> 3);                        // the writer's bx for this row
-                const uint32_t lc = e_now >> 3;                                   // lines that end at or before e_now
-                if(8u * lc > e_prev && 8u * lc >= S + 8u) {                       // a whole line of this row just completed
-                    const uint32_t ac = 8u * (lc - 1u) + (uint32_t)c;
-                    store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
-                }
-                if(it == 0 && (S & 7u)) {                                         // head: the row starts inside a line
-                    const uint32_t ac = (S & ~7u) + (uint32_t)c;
-                    if(ac >= S && ac < e_now && ac < ((S + 7u) & ~7u))
-                        store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
-                }
-                if(it == n_it - 1 && (e_now & 7u)) {                              // tail: the row ends inside a line
-                    const uint32_t ac = (e_now & ~7u) + (uint32_t)c;
-                    if(ac < e_now && ac >= S && (e_now & ~7u) >= ((S + 7u) & ~7u))
-                        store_streaming(out + (size_t)ac * 8, ring[wave][xl * 16 + ((ac ^ sw_x) & 15u)]);
-                }
+                store_streaming(out + (size_t)R * H + (size_t)px, lds[xl * RUN + ((q - xl * RUN) ^ (xl >> 3))]);
             }
         }
-        wave_lds_fence();
-        y0 = y0_next;
-        inside = inside_next;
     }
 }
 
