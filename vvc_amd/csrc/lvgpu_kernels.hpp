@@ -487,7 +487,9 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
     const uint32_t bpf = tiles_x * cols_y;
     const uint32_t f = blk / bpf;
     const uint32_t t = blk - f * bpf;
-    const uint32_t cy = t / tiles_x, tx = t - cy * tiles_x;   // neighbours in x follow each other: whole source rows stream
+    // the blocks of a column follow each other: their runs join into whole panel rows while the lines they share are
+    // still in L2 (3840x2160: rotation alone 60.7 -> 63.8 %, fused 64.1 -> 64.8 % against row-major block order)
+    const uint32_t tx = t / cols_y, cy = t - tx * cols_y;
     constexpr bool BLEND = SRC != SRC_COPY;
     constexpr int RUN = 8 * COL_WPB;                           // 16-byte chunks per output run
     const bool r90 = a.rot == 1;
