@@ -68,13 +68,16 @@ int main()
                     if(ref_scene_display(w, h, (void *)lvgpu_draw_ctx_init, (void *)lvgpu_draw_ctx_deinit, lvgpu_draw_ctx_size(),
                                          nullptr, nullptr, 1, flags) != 0)
                         return 3;
-                    ref_scene_build(scene);
-                    ref_scene_refresh();
-                    if(memcmp(ref_scene_fb(), sw.data(), bytes) != 0) {
-                        fprintf(stderr, "frame differs: deferred %d scene %d flags %d %dx%d\n", deferred, scene, flags, w, h);
-                        return 4;
+                    for(int rep = 0; rep < 4; rep++) {  // deferred mode: plan, compile + replay, replay, replay
+                        ref_scene_build(scene);
+                        ref_scene_refresh();
+                        if(memcmp(ref_scene_fb(), sw.data(), bytes) != 0) {
+                            fprintf(stderr, "frame differs: deferred %d scene %d flags %d %dx%d refresh %d\n", deferred, scene, flags, w,
+                                    h, rep);
+                            return 4;
+                        }
+                        checked++;
                     }
-                    checked++;
                     if(flags & 2) continue;  // the flush callback takes lv_color_t buffers only
                     // both plug-in points
                     for(int rot = 0; rot <= 3; rot++) {
@@ -87,11 +90,14 @@ int main()
                         if(ref_scene_display(w, h, (void *)lvgpu_draw_ctx_init, (void *)lvgpu_draw_ctx_deinit, lvgpu_draw_ctx_size(),
                                              (void *)lvgpu_flush_cb, &cfg, 1, flags) != 0)
                             return 5;
-                        ref_scene_build(scene);
-                        ref_scene_refresh();
-                        if(memcmp(ref_scene_draw_buf(), sw.data(), bytes) != 0) {
-                            fprintf(stderr, "draw buffer differs: deferred %d scene %d flags %d rot %d\n", deferred, scene, flags, rot);
-                            return 6;
+                        for(int rep = 0; rep < 3; rep++) {
+                            ref_scene_build(scene);
+                            ref_scene_refresh();
+                            if(memcmp(ref_scene_draw_buf(), sw.data(), bytes) != 0) {
+                                fprintf(stderr, "draw buffer differs: deferred %d scene %d flags %d rot %d refresh %d\n", deferred, scene,
+                                        flags, rot, rep);
+                                return 6;
+                            }
                         }
                         ref_scene_display(16, 16, nullptr, nullptr, 0, nullptr, nullptr, 1, 0);  // cfg goes out of scope
                         checked++;
@@ -103,9 +109,10 @@ int main()
     ref_scene_display(16, 16, nullptr, nullptr, 0, nullptr, nullptr, 1, 0);
     lvgpu_lvgl_stats_t st;
     lvgpu_lvgl_get_stats(&st);
-    printf("drop-in checker ok: %d renders identical to LVGL's software renderer, %llu blends on the GPU, %llu lists, %llu flushes, "
-           "%lld pixels handed to the sink\n",
-           checked, (unsigned long long)st.blend_gpu, (unsigned long long)st.blend_lists, (unsigned long long)st.flush_gpu, g_sunk);
+    printf("drop-in checker ok: %d renders identical to LVGL's software renderer, %llu blends on the GPU, %llu lists (%llu replayed), "
+           "%llu flushes, %lld pixels handed to the sink\n",
+           checked, (unsigned long long)st.blend_gpu, (unsigned long long)st.blend_lists, (unsigned long long)st.list_replays,
+           (unsigned long long)st.flush_gpu, g_sunk);
     fflush(stdout);
     _exit(0);  // the sanitizer runtime of this toolchain trips over the HIP runtime's own unload order at exit
 }
