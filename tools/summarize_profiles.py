@@ -121,7 +121,7 @@ if traffic:
                "kernel_sources_sha": bench.kernel_sources_sha(), "workloads": traffic},
               open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 
-# display-list kernel with its issue counters (tools/collect_list_profile.sh): kept as in round 1
+# display-list kernel with its issue counters (tools/collect_list_profile.sh)
 lsrc = os.path.join(src, "list")
 if os.path.isdir(lsrc):
     st = newest(os.path.join(lsrc, "kt", "**", "*_kernel_stats.csv"))
