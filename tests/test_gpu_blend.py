@@ -269,3 +269,36 @@ def test_argb8565_destination_every_alpha_pair(gpu, oracle, swap):
                                                        mask_buf=to_dev(mask), opa=opa))
                 assert gpu.last_kernel() == kernel
                 assert np.array_equal(to_np(d, np.uint8), exp), (opa, use_src, kernel)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_translucent_fill_many_frames_one_block_per_frame(gpu, oracle, swap):
+    """With thousands of frames the first-non-black pre-pass runs one workgroup per frame over the whole area (with few
+    frames: several segments per frame); frames whose first non-black pixel lies beyond the first 1024-pixel piece,
+    all-black frames, and a clipped area whose rows are not contiguous."""
+    rng = np.random.default_rng(91 + swap)
+    color, opa = (0xD67F, 137) if swap else (0x2EDE, 103)   # the two formulas disagree on black for these
+    N, H, W = 3000, 40, 72
+    dst = rng.integers(1, 65536, (N, H, W), dtype=np.uint16)
+    flat = dst.reshape(N, -1)
+    for f in range(N):
+        k = f % 5
+        if k == 0:
+            flat[f, : int(rng.integers(1, H * W))] = 0
+        elif k == 1:
+            flat[f, :] = 0
+        elif k == 2:
+            flat[f, : 1024 + int(rng.integers(0, 1500))] = 0   # the first piece holds nothing but black
+        elif k == 3:
+            flat[f, rng.random(H * W) < 0.7] = 0
+    for clip in ((0, 0, W - 1, H - 1), (5, 3, 60, 37)):
+        exp = dst.copy()
+        buf_area = (0, 0, W - 1, H - 1)
+        for f in range(N):
+            oracle.blend(exp[f], buf_area, clip, buf_area, color=color, opa=opa, swap=swap)
+        d = to_dev(dst)
+        gpu.lv_draw_sw_blend(gpu.DrawCtx(d, buf_area, clip, color_16_swap=swap), gpu.BlendDsc(buf_area, color=color, opa=opa))
+        assert gpu.last_kernel() == ("k_blend_linear" if clip[0] == 0 else "k_blend_rows")
+        got = to_np(d, np.uint16)
+        bad = np.flatnonzero((got != exp).reshape(N, -1).any(axis=1))
+        assert bad.size == 0, "frames %s differ" % bad[:8]

@@ -76,8 +76,7 @@ struct Queue {
     size_t fb_cap = 0;
     void * d_arena = nullptr;
     size_t arena_cap = 0;
-    // Host draw buffers registered with the runtime (hipHostRegister) so that they travel by DMA; LVGL has one or two
-    // per display plus its layers' buffers, which come and go: a small table, oldest entry replaced.
+    // The display's draw buffers (one or two), registered with the runtime (hipHostRegister) so that they travel by DMA.
     struct Reg {
         void * p;
         size_t bytes;
@@ -236,7 +235,11 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         HIP_OR_DIE(hipMalloc(&q->d_arena, q->arena_cap));
     }
     hipStream_t st = s->stream;
-    ensure_registered(q, q->buf, fb_bytes);
+    // Only the display's own draw buffers are registered: they live as long as the display (and this context) does.
+    // Layer buffers are allocated and freed by LVGL per layer; a registration that outlived such a buffer would keep
+    // pointing at pages the allocator has handed to someone else.
+    const lvgpu_lv_disp_draw_buf_t * db = s->drv ? s->drv->draw_buf : nullptr;
+    if(db && (q->buf == db->buf1 || q->buf == db->buf2) && fb_bytes <= (size_t)db->size * bpp) ensure_registered(q, q->buf, fb_bytes);
     if(!q->covered) HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
     if(q->arena.size) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data, q->arena.size, hipMemcpyHostToDevice, st));
 
