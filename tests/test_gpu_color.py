@@ -41,6 +41,15 @@ def test_color_fill_and_buffer_copy(gpu):
     buf = torch.zeros(12345, dtype=torch.int16, device="cuda")
     gpu.color_fill(buf, 0xA5C3)
     assert bool((buf.view(torch.int16) == np.int16(np.uint16(0xA5C3).view(np.int16))).all())
+    # lv_color_fill over every start alignment and length around the 16-byte words: nothing outside [lo, lo + n) changes
+    guard = np.int16(0x1357)
+    c = np.int16(np.uint16(0xBEEF).view(np.int16))
+    for lo in range(0, 9):
+        for n in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1000, 4099):
+            big = torch.full((lo + n + 40,), int(guard), dtype=torch.int16, device="cuda")
+            gpu.color_fill(big[lo:lo + n], 0xBEEF)
+            h = big.cpu().numpy()
+            assert (h[:lo] == guard).all() and (h[lo + n:] == guard).all() and (h[lo:lo + n] == c).all(), (lo, n)
     rng = np.random.default_rng(1)
     N = 3
     src = rng.integers(0, 65536, (N, 20, 33), dtype=np.uint16)
@@ -109,3 +118,53 @@ def test_image_convert_recolor_chroma_key(gpu, oracle, swap):
         gpu.lv_draw_sw_blend(ctx, dsc)
         got = to_np(d, np.uint16)
         assert np.array_equal(got[0], out) and np.array_equal(got[1], out), (k, cf, recolor_opa, opa)
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_conversions_at_any_alignment_and_length(gpu, oracle, swap):
+    """The conversion entry points take 8 pixels per lane when their buffers are 16-byte aligned, pixel by pixel
+    otherwise and for what is left over: every combination of misaligned input / output and of lengths around a
+    multiple of 8 gives the oracle's values and leaves the bytes beside the output alone."""
+    from vvc_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(17 + swap)
+    for n in (1, 7, 8, 9, 64, 1001, 4099):
+        for in_off, out_off in ((0, 0), (1, 0), (0, 1), (3, 5)):
+            x = rng.integers(0, 1 << 24, n + in_off, dtype=np.uint32)
+            exp = np.empty(n, np.uint16)
+            oracle.lib().lvref_color_hex_n(oracle._p(x[in_off:].copy()), oracle._p(exp), n, swap)
+            dx = to_dev(x)
+            out = torch.full((n + out_off + 9,), 0x1111, dtype=torch.int16, device="cuda")
+            assert L.lvgpu_color_from_rgb888(dx.data_ptr() + 4 * in_off, out.data_ptr() + 2 * out_off, n, swap, None) == 0
+            h = to_np(out, np.uint16)
+            assert np.array_equal(h[out_off:out_off + n], exp) and (h[:out_off] == 0x1111).all() and (h[out_off + n:] == 0x1111).all()
+            c = rng.integers(0, 65536, n + in_off, dtype=np.uint16)
+            exp32 = np.empty(n, np.uint32)
+            oracle.lib().lvref_color_to32_n(oracle._p(c[in_off:].copy()), oracle._p(exp32), n, swap)
+            out32 = torch.full((n + out_off + 9,), 0x22222222, dtype=torch.int32, device="cuda")
+            assert L.lvgpu_color_to32(to_dev(c).data_ptr() + 2 * in_off, out32.data_ptr() + 4 * out_off, n, swap, None) == 0
+            h32 = to_np(out32, np.uint32)
+            assert np.array_equal(h32[out_off:out_off + n], exp32) and (h32[:out_off] == 0x22222222).all() and \
+                (h32[out_off + n:] == 0x22222222).all()
+            for fmt in (1, 2, 4):
+                if fmt == 1:
+                    src = rng.integers(0, 65536, n + in_off, dtype=np.uint16)
+                    sview, sbytes = src[in_off:], 2 * in_off
+                elif fmt == 2:
+                    src = rng.integers(0, 1 << 32, n + in_off, dtype=np.uint32)
+                    sview, sbytes = src[in_off:], 4 * in_off
+                else:
+                    src = rng.integers(0, 256, (n + in_off, 3), dtype=np.uint8)
+                    sview, sbytes = src[in_off:], 3 * in_off
+                ec, ea = oracle.image_convert(np.ascontiguousarray(sview), fmt, swap, recolor=0x3D2A, recolor_opa=90)
+                col = torch.full((n + out_off + 9,), 0x1111, dtype=torch.int16, device="cuda")
+                alp = torch.full((n + out_off + 9,), 0x33, dtype=torch.uint8, device="cuda")
+                o = _lib.ImageOpts()
+                o.recolor, o.recolor_opa = 0x3D2A, 90
+                import ctypes as C
+                assert L.lvgpu_image_convert(to_dev(src).data_ptr() + sbytes, fmt, col.data_ptr() + 2 * out_off,
+                                             alp.data_ptr() + out_off, n, swap, C.byref(o), None) == 0
+                hc, ha = to_np(col, np.uint16), to_np(alp, np.uint8)
+                assert np.array_equal(hc[out_off:out_off + n], ec) and np.array_equal(ha[out_off:out_off + n], ea), (n, in_off, out_off, fmt)
+                assert (hc[:out_off] == 0x1111).all() and (hc[out_off + n:] == 0x1111).all()
+                assert (ha[:out_off] == 0x33).all() and (ha[out_off + n:] == 0x33).all()

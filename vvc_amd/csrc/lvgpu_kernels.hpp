@@ -278,6 +278,14 @@ __device__ __forceinline__ void store_streaming(uint16_t * p, uint4 v)
     u32x4_t t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(p));
 }
+// The same with the line also dropped from the L2 once written (sc1): for launches that only write their
+// destination (opaque fill, opaque map).  A plain device copy moves 81 % of the HBM peak with these stores against
+// 78 % with nt alone and 76 % with plain ones; kernels that read what they write gain nothing from it.
+__device__ __forceinline__ void store_write_once(uint16_t * p, uint4 v)
+{
+    u32x4_t t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
+}
 
 // The LDS exchange areas are private to one wavefront.  A wave executes its LDS instructions in order, so a read
 // that follows a write in program order sees it; all that is needed is to keep the compiler from reordering the
@@ -311,6 +319,7 @@ constexpr int LIN_CHUNK = 256 * LIN_UNROLL;  // groups per block
 template <int SRC>
 __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf, uint32_t cpf)
 {
+    const int fast = fast_path<SRC>(a);
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t f = blk / cpf;
     const uint32_t c = blk - f * cpf;
@@ -318,7 +327,6 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
     const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
     const long long src_px0 = (long long)f * a.src_fs;
     const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-    const int fast = fast_path<SRC>(a);
     const uint32_t g0 = c * LIN_CHUNK + threadIdx.x;
 
     uint4 d[LIN_UNROLL];
@@ -344,7 +352,8 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
             uint4 r = d[u];
             if(BLEND) {
                 r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], g * 8, fnb);
-                *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
+                if(fast == FAST_OPAQUE) store_write_once(dst + (size_t)g * 8, r);
+                else *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.out) {
                 uint16_t * out = a.out + (long long)f * a.out_fs;
@@ -1161,25 +1170,6 @@ __global__ void k_to32(const uint16_t * in, uint32_t * out, size_t n, int swap)
         out[i] = px_to32(swap ? px_swap16(c) : c);
     }
 }
-__global__ void k_image_split(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap)
-{
-    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        uint32_t c, al;
-        if(fmt == SRC_ARGB8565) {
-            const uint8_t * p = reinterpret_cast<const uint8_t *>(src) + i * 3;
-            c = p[0] | (p[1] << 8);  // already in the buffer's byte order (lv_draw_sw_img.c:263)
-            al = p[2];
-        }
-        else {
-            uint32_t v = reinterpret_cast<const uint32_t *>(src)[i];
-            c = fmt == SRC_ARGB8888 ? px_from_argb8888(v) : px_from_rgba8888(v);
-            if(swap) c = px_swap16(c);
-            al = v >> 24;
-        }
-        color[i] = (uint16_t)c;
-        alpha[i] = (uint8_t)al;
-    }
-}
 // convert_cb + recolor: fmt SRC_RGB565 copies the colour (alpha 255, or 0 where it equals the chroma key); rc.opa_inv
 // == 255 means "no recolor" (lv_color_mix_premult with nothing premultiplied and mix 255 would not be the identity
 // in general, so it is skipped as the reference skips it).
@@ -1212,21 +1202,81 @@ __global__ void k_image_convert(const void * src, int fmt, uint16_t * color, uin
         alpha[i] = (uint8_t)al;
     }
 }
-__global__ void k_fill16(uint16_t * buf, uint16_t color, size_t n)
+// Vector forms of the conversions above: a lane converts 8 consecutive pixels with 16-byte accesses (alpha: 8 bytes);
+// n8 = number of 8-pixel groups, all pointers aligned to their access size.  The blocks of an XCD take one contiguous
+// eighth of the buffer.  What is left over (fewer than 8 pixels, or buffers that are not aligned) takes the scalar kernels.
+__global__ __launch_bounds__(256) void k_from_rgb888_v(const uint4 * in, uint4 * out, size_t n8, int swap)
 {
-    for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) buf[i] = color;
+    for(size_t g = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
+        const uint4 a = in[2 * g], b = in[2 * g + 1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for(int i = 0; i < 4; i++) o[i] = px_swap16x2_if(px_from_argb8888(w[2 * i]) | (px_from_argb8888(w[2 * i + 1]) << 16), swap);
+        out[g] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
-__global__ void k_buffer_copy(uint16_t * dst, long long dst_fs, int dst_stride, const uint16_t * src, long long src_fs,
-                              int src_stride, int w, int h, int n_frames)
+__global__ __launch_bounds__(256) void k_to32_v(const uint4 * in, uint4 * out, size_t n8, int swap)
 {
-    const uint32_t area = (uint32_t)w * (uint32_t)h;
-    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if(idx >= area) return;
-    const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
-    for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y)
-        dst[(long long)f * dst_fs + (size_t)y * dst_stride + x] = src[(long long)f * src_fs + (size_t)y * src_stride + x];
+    for(size_t g = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
+        const uint4 v = in[g];
+        const uint32_t w[4] = {px_swap16x2_if(v.x, swap), px_swap16x2_if(v.y, swap), px_swap16x2_if(v.z, swap), px_swap16x2_if(v.w, swap)};
+        uint32_t o[8];
+#pragma unroll
+        for(int i = 0; i < 4; i++) {
+            o[2 * i] = px_to32(w[i] & 0xFFFFu);
+            o[2 * i + 1] = px_to32(w[i] >> 16);
+        }
+        out[2 * g] = make_uint4(o[0], o[1], o[2], o[3]);
+        out[2 * g + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+// convert_cb + recolor (and, without key and recolor, the plain colour/alpha split); key_native: the chroma key as a
+// native value (the comparison is between stored pixels, and byte order is a bijection)
+template <int SRC>
+__global__ __launch_bounds__(256) void k_image_convert_v(const void * src, uint4 * color, uint2 * alpha, size_t n8, int swap, int keyed,
+                                                         uint32_t key_native, int recolor, PremultFill rc)
+{
+    for(size_t g = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
+        uint32_t sw[SrcWords<SRC>::N];
+        load_src<SRC>(src, (long long)g * 8, sw);
+        uint32_t c[4], al[2] = {0, 0};
+#pragma unroll
+        for(int j = 0; j < 8; j++) {
+            uint32_t fg = 0, m = 255u;
+            src_px<SRC>(sw, j, swap, fg, m);
+            if(SRC == SRC_RGB565) m = (keyed && fg == key_native) ? 0u : 255u;
+            if(j & 1) c[j >> 1] |= fg << 16;
+            else c[j >> 1] = fg;
+            al[j >> 2] |= m << ((j & 3) * 8);
+        }
+#pragma unroll
+        for(int i = 0; i < 4; i++) {
+            if(recolor) c[i] = px_mix_premult_x2(rc, c[i]);
+            c[i] = px_swap16x2_if(c[i], swap);
+        }
+        color[g] = make_uint4(c[0], c[1], c[2], c[3]);
+        alpha[g] = make_uint2(al[0], al[1]);
+    }
 }
 
+// lv_color_fill: a lane stores one 16-byte-aligned word of 8 pixels (write-once stores); the words at the two ends of
+// a buffer that does not start or end on a 16-byte boundary are stored pixel by pixel, inside the buffer only.
+// n_words counts the aligned words the buffer touches, first_px = pixels of the first word that lie before buf.
+__global__ __launch_bounds__(256) void k_fill16(uint16_t * word0, uint32_t first_px, uint16_t color, size_t n, size_t n_words)
+{
+    const uint32_t c2 = (uint32_t)color * 0x00010001u;
+    const uint4 v = make_uint4(c2, c2, c2, c2);
+    for(size_t w = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; w < n_words; w += (size_t)gridDim.x * 256) {
+        const long long lo = (long long)w * 8 - first_px;        // index in buf of the word's first pixel
+        uint16_t * p = word0 + w * 8;
+        if(lo >= 0 && (size_t)lo + 8 <= n) store_write_once(p, v);
+        else {
+            const int j0 = lo < 0 ? (int)-lo : 0, j1 = (long long)n - lo < 8 ? (int)((long long)n - lo) : 8;
+            store_group_masked(p, v, ((1u << j1) - 1u) & ~((1u << j0) - 1u));
+        }
+    }
+}
 __device__ __forceinline__ uint32_t ui_alpha(uint64_t h)
 {
     uint32_t t = (uint32_t)(h >> 56) % 3u;
