@@ -319,7 +319,9 @@ def main(argv=None):
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if env_world > 1 and not one_dev and torch.cuda.device_count() < env_world:
         sys.exit("bench.py: %d ranks but %d GPU(s) visible" % (env_world, torch.cuda.device_count()))
-    rank, world, local_rank, dist = sharding.init(backend if env_world > 1 else None)
+    # LVGPU_BENCH_FORCE_DIST=1: join a process group even as the only rank (rehearses the RCCL calls on one GPU)
+    force_dist = os.environ.get("LVGPU_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    rank, world, local_rank, dist = sharding.init(backend if (env_world > 1 or force_dist) else None, force=force_dist)
     if args.gpus > 1 and args.gpus != world:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)

@@ -38,3 +38,16 @@ def test_a_failing_rank_fails_the_command(gpu):
     p = _bench("--gpus", "2", "--frames-per-gpu", "64", "--steps", "1", "--warmup", "1", "--workload", "scene", "--width", "64")
     assert p.returncode != 0                               # the scene workload rejects other sizes: every rank asserts
     assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_one_rank_over_rccl(gpu):
+    """The collective calls of a multi-GPU run (barrier, max over ranks, gather of the per-rank times) over RCCL itself,
+    with a world of one rank on this one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("LVGPU_BENCH_BACKEND", "LVGPU_BENCH_ONE_DEVICE")}
+    env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29733",
+                "LVGPU_BENCH_FORCE_DIST": "1"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames-per-gpu", "256", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-eighth"], env=env, capture_output=True, timeout=420)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["roofline"]["kernel"] == "k_tile(fused)"

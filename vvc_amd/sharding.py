@@ -18,10 +18,11 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend=None):
-    """Join the process group described by the torchrun environment.  Returns (rank, world, local_rank, dist|None)."""
+def init(backend=None, force=False):
+    """Join the process group described by the torchrun environment.  Returns (rank, world, local_rank, dist|None).
+    A world of one rank needs no group unless force is set (used to rehearse the RCCL path on a single GPU)."""
     rank, world, local_rank = env_rank()
-    if world == 1:
+    if world == 1 and not force:
         return rank, world, local_rank, None
     import torch.distributed as dist
     if backend is None:
