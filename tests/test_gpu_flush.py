@@ -20,7 +20,7 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     fast = W % 8 == 0 and H % 8 == 0
     quarter = ("k_tile_col" if H % 32 else "k_tile")  # heights off the 32-px grid: a column of tiles per workgroup
     if rot in (1, 3):
-        assert gpu.last_kernel() == (quarter if fast else "k_rotate_tile_any")  # the latter: sizes off the 8-pixel grid
+        assert gpu.last_kernel() == (quarter if fast else "k_tile_any")  # the latter: sizes off the 8-pixel grid
     else:  # a copy / reversal only needs the frame to be a whole number of 8-pixel groups
         assert gpu.last_kernel() == ("k_blend_linear" if (W * H) % 8 == 0 else "k_rotate_generic")
     got = to_np(out, np.uint16).reshape(N, -1)
@@ -158,3 +158,46 @@ def test_rotate_against_lvgl_own_sw_rotate(gpu, swap):
             lvgl = z["lv_rot%d_%dx%d" % (lv_rot, LW, LH)].ravel()
             for f in range(3):
                 assert np.array_equal(out[f], lvgl), (LW, LH, lv_rot)
+
+
+@pytest.mark.parametrize("rot", [1, 3])
+@pytest.mark.parametrize("shape", [(100, 37), (135, 240), (65, 129), (7, 3), (1, 1), (466, 30), (9, 513), (64, 520)])
+def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
+    """A quarter-turn flush of frames off the 8-pixel grid is still one pass with the blend (k_tile_any): every source
+    kind, both byte orders, the translucent fill with its scan-order rule, frames whose stride leaves every frame at
+    another 2-byte alignment."""
+    W, H = shape
+    N = 3
+    rng = np.random.default_rng(W * 5 + H + rot)
+    area = (0, 0, W - 1, H - 1)
+    for swap in (1, 0):
+        for fmt, opa in ((0, 255), (0, 137 if swap else 103), (1, 200), (1, 255), (2, 255), (4, 180)):
+            dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            dst[1].reshape(-1)[: (W * H) // 2] = 0           # leading black for the translucent fill
+            color = (0xD67F if swap else 0x2EDE) if opa in (137, 103) else int(rng.integers(0, 65536))
+            src = mask = None
+            if fmt == 1:
+                src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+                mask = rand_mask(rng, (N, H, W))
+            elif fmt == 2:
+                src = rng.integers(0, 1 << 32, (N, H, W), dtype=np.uint32)
+            elif fmt == 4:
+                src = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+            elif opa == 255:
+                mask = rand_mask(rng, (N, H, W))
+            exp = dst.copy()
+            for f in range(N):
+                if fmt in (2, 4):
+                    oracle.img_blend(exp[f], area, area, area, src[f], fmt, opa, swap, W)
+                else:
+                    oracle.blend(exp[f], area, area, area, src=None if src is None else src[f], color=color,
+                                 mask=None if mask is None else mask[f], opa=opa, swap=swap)
+            d = to_dev(dst)
+            dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                               mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
+            out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
+            assert gpu.last_kernel() == ("k_tile_any(fused)" if (W % 8 or H % 8) else ("k_tile_col(fused)" if H % 32 else "k_tile(fused)"))
+            assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
+            got = to_np(out, np.uint16).reshape(N, -1)
+            for f in range(N):
+                assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 1 - swap)), (swap, fmt, opa, f)

@@ -353,6 +353,19 @@ struct LaunchTileCol {
         return LVGPU_OK;
     }
 };
+template <int SRC>
+struct LaunchTileAny {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        const int W = a.w, H = a.h;
+        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * ANY_WPB - 1) / (TILE * ANY_WPB);
+        const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
+        if(n_blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
+        hipLaunchKernelGGL(k_tile_any<SRC>, dim3((uint32_t)n_blocks), dim3(64 * ANY_WPB), 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks);
+        HIP_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
 // Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
 // the tile kernel's 128-byte output runs degrade; the column kernel writes 1-KB runs.
 inline bool wants_col(const BlendArgs & a) { return (a.h % 32) != 0; }
@@ -493,16 +506,9 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
         g_last_kernel = "k_blend_linear";
         return LaunchLinear<SRC_COPY>::run(a, st);
     }
-    if(transposing) {
-        const uint32_t tiles_x = (uint32_t)(W + 63) / 64, tiles_y = (uint32_t)(H + 63) / 64;
-        const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y * (uint32_t)n_frames;
-        if(n_tiles <= 0x7FFFFFFFull) {
-            g_last_kernel = "k_rotate_tile_any";
-            hipLaunchKernelGGL(k_rotate_tile_any, dim3((uint32_t)n_tiles), dim3(256), 0, st, in, in_fs, out, out_fs, W, H, rot,
-                               swap_out ? 1 : 0, tiles_x, tiles_x * tiles_y, (uint32_t)n_tiles);
-            HIP_TRY(hipGetLastError());
-            return LVGPU_OK;
-        }
+    if(transposing) {  // any size, any alignment
+        g_last_kernel = "k_tile_any";
+        return LaunchTileAny<SRC_COPY>::run(a, st);
     }
     g_last_kernel = "k_rotate_generic";
     const uint32_t area = (uint32_t)W * (uint32_t)H;
@@ -1137,17 +1143,24 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     if(b.n_frames == 0) return LVGPU_OK;
     const bool transposing = d->rotation == LVGPU_ROT_90 || d->rotation == LVGPU_ROT_270;
     const bool out_ok = aligned(d->out, 16) && (d->out_frame_stride % 8) == 0;
-    if(r == R_WORK && out_ok && a.w == W && a.h == H) {  // the blend touches the whole buffer: one pass over memory
+    if(r == R_WORK && (out_ok || transposing) && a.w == W && a.h == H) {  // the blend touches the whole buffer: one pass over memory
         a.out = reinterpret_cast<uint16_t *>(d->out);
         a.out_fs = d->out_frame_stride;
         a.rot = d->rotation;
         a.swap_out = d->swap_bytes ? 1 : 0;
-        const bool ok = transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format);
-        if(ok) {
+        const bool ok = out_ok && (transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format));
+        // a quarter turn of a frame off the 8-pixel grid, or of misaligned buffers: still one pass (k_tile_any); the
+        // blend must cover the whole buffer row by row (dst_stride == W holds, source and mask keep their own strides)
+        const bool any = transposing && !ok;
+        if(ok || any) {
             uint32_t * owned = nullptr;
             int rc = prepare_first_nb(a, st, &owned);
             if(rc != LVGPU_OK) return rc;
-            if(transposing && wants_col(a)) {
+            if(any) {
+                g_last_kernel = "k_tile_any(fused)";
+                rc = dispatch_src<LaunchTileAny>(b.src_format, a, st);
+            }
+            else if(transposing && wants_col(a)) {
                 g_last_kernel = "k_tile_col(fused)";
                 rc = dispatch_src<LaunchTileCol>(b.src_format, a, st);
             }
