@@ -7,6 +7,14 @@ from util import rand_mask, to_dev, to_np
 pytestmark = pytest.mark.gpu
 
 
+def quarter_turn_kernel(W, H):
+    """Heights on the 32-px grid: one tile per wavefront; off it, a column of tiles per workgroup (panel rows of up to
+    256 pixels are one run of the any-size kernel's workgroup and go there); sizes off the 8-pixel grid: any-size."""
+    if W % 8 or H % 8 or (H % 32 and H <= 256):
+        return "k_tile_any"
+    return "k_tile_col" if H % 32 else "k_tile"
+
+
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3),
                                    (96, 200), (64, 40), (200, 344), (136, 72), (8, 8), (240, 135), (135, 240), (65, 129)])
@@ -17,10 +25,8 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     rng = np.random.default_rng(W * 7 + H + rot)
     frames = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
     out = gpu.flush_rotate(to_dev(frames), rot, swap_bytes=swap_bytes)
-    fast = W % 8 == 0 and H % 8 == 0
-    quarter = ("k_tile_col" if H % 32 else "k_tile")  # heights off the 32-px grid: a column of tiles per workgroup
     if rot in (1, 3):
-        assert gpu.last_kernel() == (quarter if fast else "k_tile_any")  # the latter: sizes off the 8-pixel grid
+        assert gpu.last_kernel() == quarter_turn_kernel(W, H)
     else:  # a copy / reversal only needs the frame to be a whole number of 8-pixel groups
         assert gpu.last_kernel() == ("k_blend_linear" if (W * H) % 8 == 0 else "k_rotate_generic")
     got = to_np(out, np.uint16).reshape(N, -1)
@@ -82,9 +88,9 @@ def test_blend_flush_fused(gpu, oracle, rot, swap, fmt):
 
 
 @pytest.mark.parametrize("rot", [1, 3])
-@pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216)])
+@pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216), (72, 264), (64, 520)])
 def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
-    """Heights that are not a multiple of 32 px: fused blend + rotation through the column-strip kernel."""
+    """Heights that are not a multiple of 32 px: fused blend + rotation through the column kernels."""
     W, H = shape
     N = 3
     rng = np.random.default_rng(W + H + rot)
@@ -113,7 +119,7 @@ def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
         dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
                            mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
         out = gpu.blend_flush(gpu.DrawCtx(d), dsc, rot)
-        assert gpu.last_kernel() == "k_tile_col(fused)"
+        assert gpu.last_kernel() == quarter_turn_kernel(W, H) + "(fused)"
         assert np.array_equal(to_np(d, np.uint16), exp_dst)
         got = to_np(out, np.uint16).reshape(N, -1)
         for f in range(N):
@@ -196,7 +202,7 @@ def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
             dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
                                mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
             out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
-            assert gpu.last_kernel() == ("k_tile_any(fused)" if (W % 8 or H % 8) else ("k_tile_col(fused)" if H % 32 else "k_tile(fused)"))
+            assert gpu.last_kernel() == quarter_turn_kernel(W, H) + "(fused)"
             assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
             got = to_np(out, np.uint16).reshape(N, -1)
             for f in range(N):

@@ -427,6 +427,10 @@ bool linear_ok(const BlendArgs & a, int fmt)
 // ... and additionally as whole W x H frames for the tile kernel (row starts stay 16-byte aligned).
 bool tile_ok(const BlendArgs & a, int fmt)
 {
+    // a panel row of up to 256 pixels that does not end on a 64-byte boundary is one run of k_tile_any's four-wave
+    // workgroup: ahead of k_tile_col there, whose eight waves would be half idle (320x200: 72 against 65 % rotating,
+    // 68 against 63 % fused); taller frames stay with k_tile_col (480x272 ... 3840x2160: 1 to 10 points ahead)
+    if((a.h % 32) != 0 && a.h <= TILE * ANY_WPB) return false;
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
 
