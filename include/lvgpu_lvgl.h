@@ -148,13 +148,27 @@ void lvgpu_lvgl_set_color_16_swap(int swap);
  * text renderer (draw_letter_subpx reads the destination, libraries/lvgl/src/draw/sw/lv_draw_sw_letter.c:423), so
  * the mode requires LV_USE_FONT_SUBPX 0 (the reference firmware's setting).  These two requirements -- a cooperating
  * flush_cb and no direct readers -- are why the mode is opt-in.
- * The draw buffer travels to the device only when no queued item overwrites all of it (a screen background does),
- * and comes back once per submission; a refresh that queues exactly what the previous one queued (same rectangles,
+ * A draw buffer that came from lvgpu_lvgl_buf_alloc (below) is drawn IN PLACE: the launch reads sources and masks from
+ * the queue's pinned memory and reads and writes the draw buffer (and, from lvgpu_flush_cb, writes the panel image) in
+ * host memory over the bus, so a submission is one launch and one wait (lvgpu_lvgl_stats_t.lists_in_place).  Any other
+ * buffer (LVGL's own layer buffers, a display buffer from malloc) is staged: it travels to the device only when no
+ * queued item overwrites all of it (a screen background does), and comes back once per submission;
+ * LVGPU_LVGL_STAGED in the environment stages everything.  A refresh that queues exactly what the previous one queued (same rectangles,
  * colours, opacities; mask and image bytes may differ) replays the plan made for the previous one instead of planning
  * again (lvgpu_lvgl_stats_t.list_replays).  A display with drv->sw_rotate set (LVGL rotates the draw buffer on the CPU right before flush_cb,
  * libraries/lvgl/src/core/lv_refr.c:1262-1296, with no hook in between) stays in immediate mode.
  */
 void lvgpu_lvgl_set_deferred(int on);
+
+/*
+ * Memory for the display's draw buffers (the argument of lv_disp_draw_buf_init): what the port takes from
+ * heap_caps_malloc with MALLOC_CAP_DMA when the board sets flags.buff_dma (src/lv_port.c:198-207) and releases with
+ * free (src/lv_port.c:256-258, 286-288).  Here "DMA-capable" means pinned host memory that the GPU reads and writes
+ * directly: deferred mode draws such a buffer in place, without copying it to the device and back.  For the CPU it is
+ * ordinary cached memory.  NULL when the allocation fails.  A buffer from anywhere else works too, through copies.
+ */
+void * lvgpu_lvgl_buf_alloc(size_t bytes);
+void lvgpu_lvgl_buf_free(void * p);
 
 /* drv->draw_ctx_init / draw_ctx_deinit / draw_ctx_size (libraries/lvgl/src/hal/lv_hal_disp.h:143-146).
  * init = lv_draw_sw_init_ctx, then blend and wait_for_finish are replaced. */
@@ -202,6 +216,7 @@ typedef struct {
     uint64_t blend_lists;  /* deferred mode: display lists submitted */
     uint64_t list_replays; /* ... of which drawn by replaying the plan of the previous, identical refresh */
     uint64_t submit_ns;    /* host time spent submitting (copies, planning, launch, wait), nanoseconds */
+    uint64_t lists_in_place; /* ... of blend_lists: drawn in place in host memory, without a copy in either direction */
 } lvgpu_lvgl_stats_t;
 void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out);
 void lvgpu_lvgl_reset_stats(void);

@@ -302,6 +302,8 @@ def ref(swap=1):
         L.ref_scene_build.argtypes = [C.c_int]
         if hasattr(L, "ref_scene_set_pre_flush"):
             L.ref_scene_set_pre_flush.argtypes = [C.c_void_p]
+        if hasattr(L, "ref_scene_set_buf_allocator"):
+            L.ref_scene_set_buf_allocator.argtypes = [C.c_void_p, C.c_void_p]
         if hasattr(L, "ref_record_items"):
             L.ref_record_items.restype = C.POINTER(RecItem)
             L.ref_record_ctx_size.restype = C.c_size_t

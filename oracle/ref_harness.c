@@ -352,6 +352,19 @@ REF_API void ref_scene_set_pre_flush(void * fn)
     g_pre_flush = (void (*)(lv_draw_ctx_t *))fn;
 }
 
+/* Where the display's draw buffer comes from: the port takes it from heap_caps_malloc with the capabilities the
+ * board asks for (DMA-capable memory with flags.buff_dma, src/lv_port.c:198-207) and frees it with free (:256-258,
+ * :286-288).  NULL/NULL = calloc/free. */
+static void * (*g_buf_alloc)(size_t);
+static void (*g_buf_free)(void *);
+static void (*g_buf1_free)(void *); /* what frees the current g_buf1 */
+
+REF_API void ref_scene_set_buf_allocator(void * alloc_fn, void * free_fn)
+{
+    g_buf_alloc = (void * (*)(size_t))alloc_fn;
+    g_buf_free = (void (*)(void *))free_fn;
+}
+
 static void capture_flush(lv_disp_drv_t * drv, const lv_area_t * a, lv_color_t * p)
 {
     if(g_pre_flush) g_pre_flush(drv->draw_ctx);
@@ -383,13 +396,23 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
     if(g_disp1) {
         lv_disp_remove(g_disp1);
         g_disp1 = NULL;
-        free(g_buf1);
+        if(g_buf1_free) g_buf1_free(g_buf1);
+        else free(g_buf1);
         free(g_fb1);
     }
     g_fb_w = hor_res;
     g_fb_h = ver_res;
     g_px_bytes = (flags & 2) ? LV_IMG_PX_SIZE_ALPHA_BYTE : (int)sizeof(lv_color_t);
-    g_buf1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
+    if(g_buf_alloc && g_buf_free) {
+        g_buf1 = g_buf_alloc((size_t)hor_res * ver_res * (size_t)g_px_bytes);
+        if(!g_buf1) return -1;
+        memset(g_buf1, 0, (size_t)hor_res * ver_res * (size_t)g_px_bytes);
+        g_buf1_free = g_buf_free;
+    }
+    else {
+        g_buf1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
+        g_buf1_free = NULL;
+    }
     g_fb1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
     g_flush_calls = 0;
     lv_disp_draw_buf_init(&g_dbuf1, g_buf1, NULL, (uint32_t)hor_res * ver_res);

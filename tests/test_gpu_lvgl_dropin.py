@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 class Stats(C.Structure):
     _fields_ = [("blend_gpu", C.c_uint64), ("blend_delegated", C.c_uint64), ("flush_gpu", C.c_uint64),
-                ("errors", C.c_uint64), ("blend_lists", C.c_uint64), ("list_replays", C.c_uint64), ("submit_ns", C.c_uint64)]
+                ("errors", C.c_uint64), ("blend_lists", C.c_uint64), ("list_replays", C.c_uint64), ("submit_ns", C.c_uint64),
+                ("lists_in_place", C.c_uint64)]
 
 
 class FlushCfg(C.Structure):
@@ -27,10 +28,12 @@ def _addr(fn):
     return C.cast(fn, C.c_void_p)
 
 
-@pytest.fixture(scope="module", params=[(1, 0), (0, 0), (1, 1), (0, 1)], ids=["swap1", "swap0", "swap1-deferred",
-                                                                               "swap0-deferred"])
+@pytest.fixture(scope="module", params=[(1, 0), (0, 0), (1, 1), (0, 1), (1, 2)],
+                ids=["swap1", "swap0", "swap1-deferred", "swap0-deferred", "swap1-deferred-staged"])
 def world(request, gpu, oracle):
-    """(LV_COLOR_16_SWAP, deferred): deferred = blend calls are queued and drawn as one display list per flush."""
+    """(LV_COLOR_16_SWAP, deferred): deferred = blend calls are queued and drawn as one display list per flush -- in place
+    when the display's draw buffer comes from lvgpu_lvgl_buf_alloc (1), through device copies when it comes from
+    calloc (2)."""
     swap, deferred = request.param
     R = oracle.ref(swap)
     if R is None:
@@ -39,10 +42,13 @@ def world(request, gpu, oracle):
     L = _lib.lib()
     L.lvgpu_lvgl_bind(_addr(R.lv_draw_sw_init_ctx), _addr(R.lv_draw_sw_blend_basic), _addr(R.lv_disp_flush_ready))
     L.lvgpu_lvgl_set_color_16_swap(swap)
-    L.lvgpu_lvgl_set_deferred(deferred)
+    L.lvgpu_lvgl_set_deferred(1 if deferred else 0)
+    if deferred == 1:  # what a port does where the reference asks heap_caps_malloc for DMA-capable memory
+        R.ref_scene_set_buf_allocator(_addr(L.lvgpu_lvgl_buf_alloc), _addr(L.lvgpu_lvgl_buf_free))
     # the harness' own flush_cb does what a driver with its own flush_cb has to do in deferred mode
     R.ref_scene_set_pre_flush(_addr(L.lvgpu_wait_for_finish) if deferred else None)
     yield swap, R, L
+    R.ref_scene_set_buf_allocator(None, None)
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)  # drop the GPU context before the library goes away
     R.ref_scene_set_pre_flush(None)
     L.lvgpu_lvgl_set_deferred(0)
@@ -87,6 +93,13 @@ def test_widget_scene_through_gpu_blend(world, scene, res, flags, request):
             assert 1 <= st.blend_lists <= 40 and st.blend_gpu > 5 * st.blend_lists
         else:
             assert 1 <= st.blend_lists <= 4 and st.blend_gpu > 100 * st.blend_lists
+        deferred = request.node.callspec.params["world"][1]
+        if deferred == 2:
+            assert st.lists_in_place == 0
+        elif scene == 3:   # layer buffers are LVGL's to allocate (ordinary memory): those lists are staged
+            assert 1 <= st.lists_in_place < st.blend_lists
+        else:              # the display's draw buffer is pinned: every list is drawn in place, no copy either way
+            assert st.lists_in_place == st.blend_lists
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])

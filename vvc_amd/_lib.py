@@ -134,6 +134,8 @@ def lib():
         "lvgpu_blend": (None, [vp, vp]),
         "lvgpu_wait_for_finish": (None, [vp]),
         "lvgpu_flush_cb": (None, [vp, vp, vp]),
+        "lvgpu_lvgl_buf_alloc": (vp, [sz]),
+        "lvgpu_lvgl_buf_free": (None, [vp]),
         "lvgpu_lvgl_get_stats": (None, [vp]),
         "lvgpu_lvgl_reset_stats": (None, []),
     }

@@ -31,7 +31,7 @@ blend_fn g_sw_blend_basic = nullptr;
 flush_ready_fn g_flush_ready = nullptr;
 int g_swap = 1;
 int g_deferred = 0;
-std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0}, g_replays{0}, g_submit_ns{0};
+std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0}, g_replays{0}, g_submit_ns{0}, g_in_place{0};
 
 typedef void * (*layer_init_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
 typedef void (*layer_adjust_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
@@ -76,16 +76,12 @@ struct Queue {
     size_t fb_cap = 0;
     void * d_arena = nullptr;
     size_t arena_cap = 0;
-    // The display's draw buffers (one or two), registered with the runtime (hipHostRegister) so that they travel by DMA.
-    struct Reg {
-        void * p;
-        size_t bytes;
-    };
-    std::vector<Reg> regs;
     // A refresh that queues exactly what the previous one queued (same rectangles, opacities, colours, arena layout --
     // the usual case for a UI between two changes of its layout; the bytes of the masks and images may differ) is drawn
     // by replaying the list planned for the previous one.
     std::vector<QItem> prev_items;
+    const void * prev_fb = nullptr;     // where the previous submit's launch drew (device address) ...
+    const void * prev_arena = nullptr;  // ... and read its sources and masks from
     void * prev_buf = nullptr;
     lvgpu_area_t prev_area{0, 0, 0, 0};
     bool prev_transp = false;
@@ -149,24 +145,16 @@ uint8_t * PinnedArena::grow_to(size_t new_size)
     return data;
 }
 
-// Is [p, p + bytes) registered with the runtime?  Registers it if not (a failure is not an error: the copy then goes
-// through the runtime's own staging).
-void ensure_registered(Queue * q, void * p, size_t bytes)
+// The address under which the device sees a piece of pinned host memory (lvgpu_lvgl_buf_alloc, the queue's arena, the
+// flush staging); nullptr for ordinary memory.
+void * device_view(void * host)
 {
-    for(const Queue::Reg & r : q->regs)
-        if(r.p == p && r.bytes >= bytes) return;
-    for(size_t i = 0; i < q->regs.size(); i++)
-        if(q->regs[i].p == p) {  // the same buffer with another size: register again
-            (void)hipHostUnregister(p);
-            q->regs.erase(q->regs.begin() + (long)i);
-            break;
-        }
-    if(q->regs.size() >= 8) {
-        (void)hipHostUnregister(q->regs.front().p);
-        q->regs.erase(q->regs.begin());
+    void * d = nullptr;
+    if(host == nullptr || hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    if(hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) q->regs.push_back(Queue::Reg{p, bytes});
-    else (void)hipGetLastError();
+    return d;
 }
 
 void drop_compiled(Queue * q)
@@ -211,9 +199,15 @@ struct FlushReq {
     int rot, swap_bytes;
 };
 
-// Submit the queue: draw buffer to the device (unless a queued item overwrites all of it), the whole list in one
-// launch, draw buffer back.  With fr the same launch also writes the rotated panel image (the tiles are flushed from
-// on-chip memory) and it comes back too.
+// Submit the queue: the whole list in one launch.  With fr the same launch also writes the rotated panel image (the
+// tiles are flushed from on-chip memory).
+// In place (a draw buffer in pinned memory, i.e. one that came from lvgpu_lvgl_buf_alloc): the launch reads the
+// sources and masks from the pinned arena, reads the draw buffer where no queued item overwrites it, and writes the
+// buffer and the panel image, all in host memory over the bus -- no copy is issued, the submission is one launch and
+// one wait.
+// Staged (any other buffer: LVGL's own layer buffers, a display buffer from malloc; or LVGPU_LVGL_STAGED in the
+// environment): arena and, unless a queued item overwrites all of it, draw buffer to the device, the launch, draw
+// buffer and panel image back.
 void submit(ShimCtx * s, const FlushReq * fr = nullptr)
 {
     Queue * q = s->q;
@@ -222,30 +216,40 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
     const int W = q->buf_area.x2 - q->buf_area.x1 + 1, H = q->buf_area.y2 - q->buf_area.y1 + 1;
     const size_t bpp = q->transp ? 3 : 2;
     const size_t fb_bytes = (size_t)W * H * bpp;
-    if(fb_bytes > q->fb_cap) {
-        drop_compiled(q);
-        if(q->d_fb) HIP_OR_DIE(hipFree(q->d_fb));
-        HIP_OR_DIE(hipMalloc(&q->d_fb, fb_bytes));
-        q->fb_cap = fb_bytes;
-    }
-    if(q->arena.size > q->arena_cap) {
-        drop_compiled(q);
-        if(q->d_arena) HIP_OR_DIE(hipFree(q->d_arena));
-        q->arena_cap = q->arena.size * 2;
-        HIP_OR_DIE(hipMalloc(&q->d_arena, q->arena_cap));
-    }
     hipStream_t st = s->stream;
-    // Only the display's own draw buffers are registered: they live as long as the display (and this context) does.
-    // Layer buffers are allocated and freed by LVGL per layer; a registration that outlived such a buffer would keep
-    // pointing at pages the allocator has handed to someone else.
-    const lvgpu_lv_disp_draw_buf_t * db = s->drv ? s->drv->draw_buf : nullptr;
-    if(db && (q->buf == db->buf1 || q->buf == db->buf2) && fb_bytes <= (size_t)db->size * bpp) ensure_registered(q, q->buf, fb_bytes);
-    if(!q->covered) HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
-    if(q->arena.size) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data, q->arena.size, hipMemcpyHostToDevice, st));
+    void * fb = nullptr;     // where the launch draws ...
+    void * arena = nullptr;  // ... where it finds sources and masks ...
+    void * out = nullptr;    // ... and where the panel image goes
+    bool in_place = false;
+    if(getenv("LVGPU_LVGL_STAGED") == nullptr) {
+        fb = device_view(q->buf);
+        arena = q->arena.size ? device_view(q->arena.data) : nullptr;
+        out = fr ? device_view(fr->panel) : nullptr;
+        in_place = fb && (arena || q->arena.size == 0) && (!fr || out);
+    }
+    if(!in_place) {
+        if(fb_bytes > q->fb_cap) {
+            drop_compiled(q);
+            if(q->d_fb) HIP_OR_DIE(hipFree(q->d_fb));
+            HIP_OR_DIE(hipMalloc(&q->d_fb, fb_bytes));
+            q->fb_cap = fb_bytes;
+        }
+        if(q->arena.size > q->arena_cap) {
+            drop_compiled(q);
+            if(q->d_arena) HIP_OR_DIE(hipFree(q->d_arena));
+            q->arena_cap = q->arena.size * 2;
+            HIP_OR_DIE(hipMalloc(&q->d_arena, q->arena_cap));
+        }
+        fb = q->d_fb;
+        arena = q->d_arena;
+        out = fr ? fr->d_out : nullptr;
+        if(!q->covered) HIP_OR_DIE(hipMemcpyAsync(q->d_fb, q->buf, fb_bytes, hipMemcpyHostToDevice, st));
+        if(q->arena.size) HIP_OR_DIE(hipMemcpyAsync(q->d_arena, q->arena.data, q->arena.size, hipMemcpyHostToDevice, st));
+    }
 
     // the same content as the previous submit?
     const int sig = fr ? 1 + fr->rot * 2 + (fr->swap_bytes ? 1 : 0) : 0;
-    const bool same = q->prev_sig == sig && q->prev_buf == q->buf && q->prev_transp == q->transp &&
+    const bool same = q->prev_sig == sig && q->prev_buf == q->buf && q->prev_fb == fb && q->prev_arena == arena && q->prev_transp == q->transp &&
                       memcmp(&q->prev_area, &q->buf_area, sizeof(lvgpu_area_t)) == 0 && q->prev_items.size() == q->items.size() &&
                       memcmp(q->prev_items.data(), q->items.data(), q->items.size() * sizeof(QItem)) == 0;
     if(!same) {
@@ -254,6 +258,8 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         q->uncompilable = false;
         q->prev_items = q->items;
         q->prev_buf = q->buf;
+        q->prev_fb = fb;
+        q->prev_arena = arena;
         q->prev_area = q->buf_area;
         q->prev_transp = q->transp;
         q->prev_sig = sig;
@@ -270,15 +276,15 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
             const QItem & it = q->items[i];
             lvgpu_blend_batch_t & b = q->batch[i];
             memset(&b, 0, sizeof(b));
-            b.dst = q->d_fb;
+            b.dst = fb;
             b.dst_frame_stride = (int64_t)W * H;
             b.buf_area = q->buf_area;
             b.clip_area = it.area;
             b.blend_area = it.area;
             b.mask_area = it.area;
-            b.src = it.has_src ? reinterpret_cast<uint8_t *>(q->d_arena) + it.src_off : nullptr;
+            b.src = it.has_src ? reinterpret_cast<uint8_t *>(arena) + it.src_off : nullptr;
             b.src_format = it.has_src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
-            b.mask = it.has_mask ? reinterpret_cast<uint8_t *>(q->d_arena) + it.mask_off : nullptr;
+            b.mask = it.has_mask ? reinterpret_cast<uint8_t *>(arena) + it.mask_off : nullptr;
             b.mask_res = LVGPU_MASK_RES_CHANGED;
             b.n_frames = 1;
             b.color = it.color;
@@ -298,12 +304,12 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         }
     }
     if(q->compiled) {
-        rc = lvgpu_list_replay(q->compiled, nullptr, 0, fr ? fr->d_out : nullptr, (int64_t)W * H, st);
+        rc = lvgpu_list_replay(q->compiled, nullptr, 0, out, (int64_t)W * H, st);
         drawn = rc == LVGPU_OK;
         if(drawn) g_replays++;
     }
     if(!drawn && rc == LVGPU_OK)
-        rc = fr ? lvgpu_blend_list_flush_batch(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr->d_out, (int64_t)W * H,
+        rc = fr ? lvgpu_blend_list_flush_batch(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), out, (int64_t)W * H,
                                                fr->rot, fr->swap_bytes, st)
                 : lvgpu_blend_list_batch(q->batch.data(), (int32_t)q->batch.size(), st);
     if(rc != LVGPU_OK) {
@@ -311,8 +317,11 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         g_errors++;
         abort();
     }
-    HIP_OR_DIE(hipMemcpyAsync(q->buf, q->d_fb, fb_bytes, hipMemcpyDeviceToHost, st));
-    if(fr) HIP_OR_DIE(hipMemcpyAsync(fr->panel, fr->d_out, fb_bytes, hipMemcpyDeviceToHost, st));
+    if(!in_place) {
+        HIP_OR_DIE(hipMemcpyAsync(q->buf, q->d_fb, fb_bytes, hipMemcpyDeviceToHost, st));
+        if(fr) HIP_OR_DIE(hipMemcpyAsync(fr->panel, fr->d_out, fb_bytes, hipMemcpyDeviceToHost, st));
+    }
+    else g_in_place++;
     HIP_OR_DIE(hipStreamSynchronize(st));
     q->items.clear();
     q->arena.size = 0;
@@ -376,6 +385,20 @@ void lvgpu_lvgl_set_color_16_swap(int swap) { g_swap = swap ? 1 : 0; }
 
 void lvgpu_lvgl_set_deferred(int on) { g_deferred = on ? 1 : 0; }
 
+void * lvgpu_lvgl_buf_alloc(size_t bytes)
+{
+    void * p = nullptr;
+    if(bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void lvgpu_lvgl_buf_free(void * p)
+{
+    if(p) (void)hipHostFree(p);
+}
+
 size_t lvgpu_draw_ctx_size(void) { return sizeof(ShimCtx); }
 
 void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_ctx)
@@ -428,7 +451,6 @@ void lvgpu_draw_ctx_deinit(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw
             submit(s);  // e.g. a canvas or snapshot drawn through a temporary context expects its pixels now
             if(s->stream) (void)hipStreamSynchronize(s->stream);
             if(s->q->compiled) (void)lvgpu_list_destroy(s->q->compiled);
-            for(const Queue::Reg & r : s->q->regs) (void)hipHostUnregister(r.p);
             s->q->arena.release();
             if(s->q->d_fb) (void)hipFree(s->q->d_fb);
             if(s->q->d_arena) (void)hipFree(s->q->d_arena);
@@ -716,6 +738,7 @@ void lvgpu_lvgl_get_stats(lvgpu_lvgl_stats_t * out)
     out->blend_lists = g_lists;
     out->list_replays = g_replays;
     out->submit_ns = g_submit_ns;
+    out->lists_in_place = g_in_place;
 }
 void lvgpu_lvgl_reset_stats(void)
 {
@@ -726,6 +749,7 @@ void lvgpu_lvgl_reset_stats(void)
     g_lists = 0;
     g_replays = 0;
     g_submit_ns = 0;
+    g_in_place = 0;
 }
 
 }  // extern "C"
