@@ -23,6 +23,7 @@ void lv_draw_sw_blend_basic(void *, const void *);
 void lv_disp_flush_ready(void *);
 // oracle/ref_harness.c
 void ref_scene_set_pre_flush(void * fn);
+void ref_scene_set_buf_allocator(void * alloc_fn, void * free_fn);
 int ref_scene_display(int hor_res, int ver_res, void * init, void * deinit, size_t ctx_size, void * flush, void * user_data,
                       int full_refresh, int flags);
 void * ref_scene_fb(void);
@@ -51,8 +52,10 @@ int main()
     lvgpu_lvgl_set_color_16_swap(1);
     const int sizes[][2] = {{480, 320}, {320, 480}, {200, 96}};
     int checked = 0;
-    for(int deferred = 0; deferred <= 1; deferred++) {
-        lvgpu_lvgl_set_deferred(deferred);
+    for(int deferred = 0; deferred <= 2; deferred++) {   // 2: deferred with the draw buffer in pinned memory (drawn in place)
+        lvgpu_lvgl_set_deferred(deferred ? 1 : 0);
+        if(deferred == 2) ref_scene_set_buf_allocator((void *)lvgpu_lvgl_buf_alloc, (void *)lvgpu_lvgl_buf_free);
+        else ref_scene_set_buf_allocator(nullptr, nullptr);
         for(int scene = 0; scene <= 3; scene++) {
             for(int flags = 0; flags <= 2; flags++) {
                 for(auto & wh : sizes) {
@@ -106,12 +109,14 @@ int main()
             }
         }
     }
+    ref_scene_set_buf_allocator(nullptr, nullptr);
     ref_scene_display(16, 16, nullptr, nullptr, 0, nullptr, nullptr, 1, 0);
     lvgpu_lvgl_stats_t st;
     lvgpu_lvgl_get_stats(&st);
-    printf("drop-in checker ok: %d renders identical to LVGL's software renderer, %llu blends on the GPU, %llu lists (%llu replayed), "
-           "%llu flushes, %lld pixels handed to the sink\n",
+    printf("drop-in checker ok: %d renders identical to LVGL's software renderer, %llu blends on the GPU, %llu lists (%llu replayed, "
+           "%llu in place), %llu flushes, %lld pixels handed to the sink\n",
            checked, (unsigned long long)st.blend_gpu, (unsigned long long)st.blend_lists, (unsigned long long)st.list_replays,
+           (unsigned long long)st.lists_in_place,
            (unsigned long long)st.flush_gpu, g_sunk);
     fflush(stdout);
     _exit(0);  // the sanitizer runtime of this toolchain trips over the HIP runtime's own unload order at exit
