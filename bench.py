@@ -450,8 +450,19 @@ def main(argv=None):
     per_rank_dt = sharding.gather_floats(dist, own_dt)
 
     eighth = None
+    copy_gbs = None
     if rank == 0 and world == 1 and not args.no_eighth and wl in ("blend_flush", "blend", "rotate"):
         cp_out = out.view(dst.shape) if out is not None else torch.empty_like(dst)
+        # the device's empirical ceiling beside the nominal peak: a plain copy of the draw buffers (2 B read + 2 B
+        # written per pixel) through the same library, timed the same way
+        cevs = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        lvgpu.flush_rotate(dst, 0, out=cp_out)
+        cevs[0].record()
+        for i in range(7):
+            lvgpu.flush_rotate(dst, 0, out=cp_out)
+            cevs[i + 1].record()
+        torch.cuda.synchronize()
+        copy_gbs = 4 * px * n / (sorted(cevs[i].elapsed_time(cevs[i + 1]) for i in range(7))[3] / 1e3) / 1e9
         eighth = eighth_gpu(lvgpu, lambda st: step(st.value), px * n, bpp,
                             copy_on=lambda st: lvgpu.flush_rotate(dst, 0, out=cp_out, stream=st.value))
         torch.cuda.synchronize()
@@ -507,6 +518,9 @@ def main(argv=None):
             },
             "pct_hbm_peak": round(100 * achieved / HBM_PEAK_GBS, 2),
         }
+        if copy_gbs is not None:
+            res["roofline"]["measured_copy_GBs"] = round(copy_gbs, 1)
+            res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
         if world > 1:
             res["per_rank_Mpx_s"] = [round(px_per_frame * n * args.steps / t / 1e6, 1) for t in per_rank_dt]
         if eighth is not None:
