@@ -29,7 +29,7 @@ def main():
     while time.time() - t0 < budget:
         swap = int(rng.integers(0, 2))
         W = int(rng.choice([8, 16, 64, 72, 128, 200, 320, 480])) if rng.random() < 0.7 else int(rng.integers(1, 300))
-        H = int(rng.choice([1, 8, 33, 64, 96, 128, 240])) if rng.random() < 0.7 else int(rng.integers(1, 200))
+        H = int(rng.choice([1, 8, 33, 64, 96, 128, 240, 264, 328])) if rng.random() < 0.7 else int(rng.integers(1, 200))
         N = int(rng.integers(1, 4))
         area = (0, 0, W - 1, H - 1)
         it = _rand_item(rng, W, H, N, bool(rng.integers(0, 2)))
