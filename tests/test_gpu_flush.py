@@ -28,7 +28,7 @@ def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     if rot in (1, 3):
         assert gpu.last_kernel() == quarter_turn_kernel(W, H)
     else:  # a copy / reversal only needs the frame to be a whole number of 8-pixel groups
-        assert gpu.last_kernel() == ("k_blend_linear" if (W * H) % 8 == 0 else "k_rotate_generic")
+        assert gpu.last_kernel() == ("k_blend_linear" if (W * H) % 8 == 0 else "k_flush_linear_any")
     got = to_np(out, np.uint16).reshape(N, -1)
     for f in range(N):
         exp = oracle.flush_frame(frames[f], W, H, rot, swap_bytes)

@@ -514,10 +514,10 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
         g_last_kernel = "k_tile_any";
         return LaunchTileAny<SRC_COPY>::run(a, st);
     }
-    g_last_kernel = "k_rotate_generic";
+    g_last_kernel = "k_flush_linear_any";
     const uint32_t area = (uint32_t)W * (uint32_t)H;
-    dim3 grid((area + 255) / 256, std::min<uint32_t>(n_frames, 65535));
-    hipLaunchKernelGGL(k_rotate_generic, grid, dim3(256), 0, st, in, in_fs, out, out_fs, W, H, rot, swap_out ? 1 : 0, n_frames);
+    dim3 grid(((area + 7) / 8 + 255) / 256, std::min<uint32_t>(n_frames, 65535));
+    hipLaunchKernelGGL(k_flush_linear_any, grid, dim3(256), 0, st, in, in_fs, out, out_fs, area, rot, swap_out ? 1 : 0, n_frames);
     HIP_TRY(hipGetLastError());
     return LVGPU_OK;
 }

@@ -8,7 +8,7 @@
 //                    transposes it in registers and exchanges it through wave-private LDS so that both the loads
 //                    and the rotated stores are 128-byte contiguous per 8 lanes
 //   k_blend_rows   : blend over any rectangle/alignment: 16-byte-aligned destination groups, scalar row edges
-//   k_rotate_generic : rotation for sizes that are not multiples of 8, one pixel per lane
+//   k_tile_any / k_flush_linear_any : the flush for frames of any size and alignment
 #pragma once
 #include "lvgpu_px.hpp"
 
@@ -1248,35 +1248,32 @@ __global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, lo
     }
 }
 
-__global__ __launch_bounds__(256) void k_rotate_generic(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
-                                                        int W, int H, int rot, int swap_out, int n_frames)
+// Copy (rot 0) or half turn (rot 2) into the panel image for frames whose pixel count is not a multiple of 8 or whose
+// buffers are not 16-byte aligned (466x466 panels; frames packed at odd strides).  A frame's pixels are contiguous, so
+// group g of the output is pixels 8g..8g+7 of the input or their mirror image: 8 pixels per lane with under-aligned
+// 16-byte accesses; the last, short group of a frame moves pixel by pixel.
+__global__ __launch_bounds__(256) void k_flush_linear_any(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
+                                                          uint32_t area, int rot, int swap_out, int n_frames)
 {
-    const uint32_t area = (uint32_t)W * (uint32_t)H;
-    const uint32_t o = blockIdx.x * 256 + threadIdx.x;  // output index: coalesced stores
-    if(o >= area) return;
-    uint32_t x, y;
-    if(rot == 1) {  // o = x*H + (H-1-y)
-        x = o / (uint32_t)H;
-        y = (uint32_t)H - 1 - (o - x * (uint32_t)H);
-    }
-    else if(rot == 3) {  // o = (W-1-x)*H + y
-        uint32_t q = o / (uint32_t)H;
-        x = (uint32_t)W - 1 - q;
-        y = o - q * (uint32_t)H;
-    }
-    else if(rot == 2) {
-        uint32_t i = area - 1 - o;
-        y = i / (uint32_t)W;
-        x = i - y * (uint32_t)W;
-    }
-    else {
-        y = o / (uint32_t)W;
-        x = o - y * (uint32_t)W;
-    }
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t o0 = g * 8u;
+    if(o0 >= area) return;
+    const uint32_t n = min(8u, area - o0);
     for(uint32_t f = blockIdx.y; f < (uint32_t)n_frames; f += gridDim.y) {
-        uint32_t v = in[(long long)f * in_fs + (size_t)y * W + x];
-        if(swap_out) v = px_swap16(v);
-        out[(long long)f * out_fs + o] = (uint16_t)v;
+        const uint16_t * src = in + (long long)f * in_fs;
+        uint16_t * dst = out + (long long)f * out_fs + o0;
+        if(n == 8u) {
+            uint4 v = rot == 2 ? reverse_group(load16_any(src + (area - 8u - o0))) : load16_any(src + o0);
+            if(swap_out) v = swap_group(v);
+            store16_any(dst, v, true);
+        }
+        else {
+            for(uint32_t j = 0; j < n; j++) {
+                uint32_t v = rot == 2 ? src[area - 1u - o0 - j] : src[o0 + j];
+                if(swap_out) v = px_swap16(v);
+                dst[j] = (uint16_t)v;
+            }
+        }
     }
 }
 
