@@ -1,6 +1,6 @@
 #!/bin/bash
 # Address-translation counters of the fused tile kernel, the linear blend and the rotation alone (run on the GPU box):
-# UTCL1 requests, hits and misses per launch.  tools/summarize_tlb.py prints them per kernel.
+# UTCL1 requests, hits and misses per launch.  tools/summarize_counters.py gpurun_out/prof_tlb prints them per kernel.
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_tlb
 for w in blend_flush blend rotate blend_flush_4k; do
