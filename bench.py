@@ -62,8 +62,8 @@ KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_kernels.hpp", "lvgpu_list.hpp", "lvgpu_px.
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="blend_flush", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0,
                     help="frames each GPU processes (default: 4096 on one GPU -- 64 for blend_flush_4k --, "
