@@ -9,6 +9,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
     blend / rotate         the blend alone (8 B/px) / the flush rotation alone (4 B/px)
     blend_rgb565a8, blend_flush_rgb565a8   the same with a colour plane + A8 plane source (7 / 9 B/px)
     blend_flush_4k         blend_flush on 3840x2160 canvases (64 frames per GPU by default)
+    blend_flush_466        blend_flush on 466x466 frames (a round AMOLED panel's size: off the 8-pixel grid, every frame
+                           at another 4-byte alignment), 2048 frames per GPU by default
+    flush_180_466          the flush alone, half turn, on the same frames (pixel count not a multiple of 8)
     clipped_small, clipped_large   lv_draw_sw_blend of a per-frame RGB565 image + A8 mask over a clipped,
                            misaligned area (201x101 at an odd x / 468x296 at x = 3) of 480x320 buffers; pixels
                            counted are the area's (7 B/px)
@@ -50,13 +53,14 @@ MULTI_GPU_TOTAL_FRAMES = 65536  # the batch that is sharded over 2/4/8 GPUs
 WORKLOADS = {
     "blend_flush": (10, 480, 320, 4096), "blend": (8, 480, 320, 4096), "rotate": (4, 480, 320, 4096),
     "blend_rgb565a8": (7, 480, 320, 4096), "blend_flush_rgb565a8": (9, 480, 320, 4096), "scene": (4, 480, 320, 4096),
-    "blend_flush_4k": (10, 3840, 2160, 64),
+    "blend_flush_4k": (10, 3840, 2160, 64), "blend_flush_466": (10, 466, 466, 2048), "flush_180_466": (4, 466, 466, 2048),
     "clipped_small": (7, 480, 320, 4096), "clipped_large": (7, 480, 320, 4096),
     "fill_translucent": (4, 480, 320, 4096), "fill_opaque": (2, 480, 320, 4096), "map_opaque": (4, 480, 320, 4096),
     "fill_masked": (5, 480, 320, 4096), "fill_masked_argb": (7, 480, 320, 4096),
 }
 CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300)}
-KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_kernels.hpp", "lvgpu_list.hpp", "lvgpu_px.hpp")
+KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_tiles.hip", "lvgpu_rows.hip", "lvgpu_launch.hpp", "lvgpu_kernels.hpp", "lvgpu_list.hpp",
+                  "lvgpu_px.hpp")
 
 
 def parse(argv=None):
@@ -345,7 +349,9 @@ def main(argv=None):
     keep = []          # tensors the descriptors point into
 
     out = None
-    wants_out = wl in ("blend_flush", "blend_flush_rgb565a8", "blend_flush_4k", "rotate", "scene")
+    wants_out = wl in ("blend_flush", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
+    if wl == "flush_180_466":
+        rot = 2
     if wl == "fill_masked_argb":
         dst = lvgpu.synth(lvgpu.SYNTH_MASK_UNI, SEED_DST, first * 3, (n, H, W, 3))
         ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap, screen_transp=1)
@@ -357,7 +363,7 @@ def main(argv=None):
         out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
 
     dsc, blist, rec = None, None, None
-    if wl in ("blend_flush", "blend", "blend_flush_4k"):
+    if wl in ("blend_flush", "blend", "blend_flush_4k", "blend_flush_466"):
         src = lvgpu.synth(argb_kind, SEED_SRC, first, (n, H, W))
         dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
     elif wl.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
@@ -406,7 +412,7 @@ def main(argv=None):
     def step(stream=None):
         if blist is not None:
             blist.replay(out=out, stream=stream)
-        elif wl == "rotate":
+        elif wl in ("rotate", "flush_180_466"):
             lvgpu.flush_rotate(dst, rot, swap_bytes=swap_bytes, out=out, stream=stream)
         else:
             prepared.run(stream)
@@ -488,6 +494,9 @@ def main(argv=None):
                             "fill_masked": "fill_normal with an A8 mask (%s), opa 255" % args.mask,
                             "fill_masked_argb": "fill_argb with an A8 mask (%s), opa 255, into a 3-byte ARGB8565 draw "
                                                 "buffer (screen_transp)" % args.mask}[wl], W, H, args.swap, n))
+        elif wl in ("rotate", "flush_180_466"):
+            desc = ("%s: the flush alone (panel image from the draw buffer), LV_COLOR_16_SWAP %d%s, %dx%d logical, rotation %d, "
+                    "%d frames per GPU" % (wl, args.swap, " (byte-swapped into wire order)" if swap_bytes else "", W, H, rot * 90, n))
         else:
             desc = ("%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d%s, %dx%d logical, "
                     "rotation %d, %d frames per GPU"

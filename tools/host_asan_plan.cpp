@@ -2,7 +2,8 @@
 // panel transactions) driven with random input against a build of the library whose HOST code carries
 // AddressSanitizer.  No GPU is needed: none of these entry points touches the device.
 //   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Xarch_host -fsanitize=address -shared \
-//         -o /tmp/asan/liblvgpu_asan.so vvc_amd/csrc/lvgpu.hip -x hip vvc_amd/csrc/lvgpu_lvgl_shim.cpp -ldl
+//         -o /tmp/asan/liblvgpu_asan.so vvc_amd/csrc/lvgpu.hip vvc_amd/csrc/lvgpu_tiles.hip \
+//         vvc_amd/csrc/lvgpu_rows.hip -x hip vvc_amd/csrc/lvgpu_lvgl_shim.cpp -ldl
 //   g++ -O1 -g -fsanitize=address -Iinclude tools/host_asan_plan.cpp -o /tmp/asan/plan_fuzz /tmp/asan/liblvgpu_asan.so
 //   ASAN_OPTIONS=detect_leaks=0 /tmp/asan/plan_fuzz 2000
 #include <cstdio>

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/lvgpu.h"
-#include "lvgpu_kernels.hpp"
+#include "lvgpu_launch.hpp"
 #include "lvgpu_list.hpp"
 
 using namespace lvgpu;
@@ -44,6 +44,13 @@ int fail(int code, const char * fmt, ...)
         hipError_t e_ = (expr);                                                                    \
         if(e_ != hipSuccess) return fail(LVGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while(0)
+}  // namespace
+
+namespace lvgpu {
+int host_fail(int code, const char * text) { return fail(code, "%s", text); }
+}  // namespace lvgpu
+
+namespace {
 
 inline int aw(const lvgpu_area_t & a) { return a.x2 - a.x1 + 1; }
 inline int ah(const lvgpu_area_t & a) { return a.y2 - a.y1 + 1; }
@@ -235,19 +242,6 @@ int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** owned, uint32_t 
     return LVGPU_OK;
 }
 
-template <template <int> class L, typename... Args>
-int dispatch_src(int fmt, Args &&... args)
-{
-    switch(fmt) {
-        case SRC_FILL: return L<SRC_FILL>::run(args...);
-        case SRC_RGB565: return L<SRC_RGB565>::run(args...);
-        case SRC_ARGB8888: return L<SRC_ARGB8888>::run(args...);
-        case SRC_RGBA8888: return L<SRC_RGBA8888>::run(args...);
-        case SRC_ARGB8565: return L<SRC_ARGB8565>::run(args...);
-        default: return L<SRC_COPY>::run(args...);
-    }
-}
-
 // How many workgroups of the full-frame blend kernels share a CU decides how many independent address streams the
 // memory system sees at once.  With the whole device streaming, fewer residents reach a higher HBM rate for the
 // plain-mix case (few instructions per byte): the linear kernel 70.3 -> 73.7 % of peak, the fused tile kernel
@@ -257,7 +251,8 @@ int dispatch_src(int fmt, Args &&... args)
 // off right above the tile kernel's value).  On a stream confined to some of the CUs (a CU mask) the same cap costs
 // 10-30 %, and the instruction-heavier blend functions lose with it everywhere, so it is applied only to the
 // launches named at its uses, on streams that own the whole device.
-constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024;
+}  // namespace
+namespace lvgpu {
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
 {
     // LVGPU_NO_RESIDENCY_CAP in the environment switches the cap off: tools/check_residency.py uses it to verify, on
@@ -281,6 +276,8 @@ uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes)
     return cus >= dev_cus ? pad_bytes : 0;
 }
 
+}  // namespace lvgpu
+namespace {
 template <int SRC>
 struct LaunchLinear {
     static int run(const BlendArgs & a, hipStream_t st)
@@ -294,23 +291,6 @@ struct LaunchLinear {
         if(fast == FAST_MIX) pad = residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS);
         // FAST_OPAQUE (opaque fill / map: write-once stores that bypass the L2) is fastest uncapped: 88 % / 77 % of peak
         hipLaunchKernelGGL(k_blend_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
-        HIP_TRY(hipGetLastError());
-        return LVGPU_OK;
-    }
-};
-template <int SRC>
-struct LaunchTile {
-    static int run(const BlendArgs & a, hipStream_t st)
-    {
-        const int W = a.w, H = a.h;
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
-        const uint32_t tpf = tiles_x * tiles_y;
-        const uint64_t n_tiles = (uint64_t)tpf * a.n_frames;
-        if(n_tiles > 0xFFFFFFF0ull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const uint32_t pad = SRC == SRC_COPY ? residency_pad(st, TILE_PAD_LDS_COPY)
-                                             : (fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, TILE_PAD_LDS) : 0);
-        hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + TILE_WPB - 1) / TILE_WPB)), dim3(64 * TILE_WPB), pad, st, a, W, H,
-                           tiles_x, tiles_y, tpf, (uint32_t)n_tiles);
         HIP_TRY(hipGetLastError());
         return LVGPU_OK;
     }
@@ -340,71 +320,9 @@ struct LaunchArgbLinear {
         return LVGPU_OK;
     }
 };
-template <int SRC>
-struct LaunchTileCol {
-    static int run(const BlendArgs & a, hipStream_t st)
-    {
-        const int W = a.w, H = a.h;
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * COL_WPB - 1) / (TILE * COL_WPB);
-        const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
-        if(n_blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        hipLaunchKernelGGL(k_tile_col<SRC>, dim3((uint32_t)n_blocks), dim3(64 * COL_WPB), 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks);
-        HIP_TRY(hipGetLastError());
-        return LVGPU_OK;
-    }
-};
-template <int SRC>
-struct LaunchTileAny {
-    static int run(const BlendArgs & a, hipStream_t st)
-    {
-        const int W = a.w, H = a.h;
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * ANY_WPB - 1) / (TILE * ANY_WPB);
-        const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
-        if(n_blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        hipLaunchKernelGGL(k_tile_any<SRC>, dim3((uint32_t)n_blocks), dim3(64 * ANY_WPB), 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks);
-        HIP_TRY(hipGetLastError());
-        return LVGPU_OK;
-    }
-};
 // Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
 // the tile kernel's 128-byte output runs degrade; the column kernel writes 1-KB runs.
 inline bool wants_col(const BlendArgs & a) { return (a.h % 32) != 0; }
-
-template <int SRC>
-struct LaunchRows {
-    static int run(const BlendArgs & a, hipStream_t st)
-    {
-        RowsMap map;
-        memset(&map, 0, sizeof(map));
-        map.groups_per_row = ((uint32_t)a.w + 7 + 7) / 8;  // the worst row alignment
-        if((a.dst_stride % 8) == 0 && (a.dst_fs % 8) == 0) {  // one alignment for every row of every frame
-            const uint32_t off = (uint32_t)((reinterpret_cast<uintptr_t>(a.dst) >> 1) & 7u);
-            map.groups_per_row = (off + (uint32_t)a.w + 7) / 8;
-        }
-        map.src_span = (long long)(a.h - 1) * a.src_stride + a.w;
-        map.mask_span = (long long)(a.h - 1) * a.mask_stride + a.w;
-        const uint64_t lanes = (uint64_t)map.groups_per_row * (uint32_t)a.h;
-        dim3 grid((uint32_t)((lanes + 256 * ROWS_UNROLL - 1) / (256 * ROWS_UNROLL)), std::min<uint32_t>(a.n_frames, 65535));
-        const uint32_t rows_pad = 0;  // no residency cap: with a row's edges handled in its own wavefronts it only loses
-        // the combinations resolve_blend produces with the normal blend function; everything else decides per pixel
-        constexpr bool own_alpha = SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888 || SRC == SRC_ARGB8565;
-        const bool normal = a.blend_fn == BF_NORMAL;
-        if(normal && a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_OPAQUE>), grid, dim3(256), rows_pad, st, a, map);
-        else if(normal && a.opa_mode == OM_CONST && !own_alpha && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_CONST>), grid, dim3(256), rows_pad, st, a, map);
-        else if(normal && a.opa_mode == OM_MASK && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MASK>), grid, dim3(256), rows_pad, st, a, map);
-        else if(normal && a.opa_mode == OM_FILL_MASK_OPA && SRC == SRC_FILL)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_FILL_MASK_OPA>), grid, dim3(256), rows_pad, st, a, map);
-        else if(normal && a.opa_mode == OM_MAP_MASK_OPA && SRC != SRC_FILL && SRC != SRC_COPY)
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_MAP_MASK_OPA>), grid, dim3(256), rows_pad, st, a, map);
-        else
-            hipLaunchKernelGGL((k_blend_rows<SRC, OM_RUNTIME>), grid, dim3(256), rows_pad, st, a, map);
-        HIP_TRY(hipGetLastError());
-        return LVGPU_OK;
-    }
-};
 
 // Can the clipped area of every frame be walked as one contiguous, 16-byte aligned run of 8-pixel groups?
 bool linear_ok(const BlendArgs & a, int fmt)
@@ -472,7 +390,7 @@ int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false, 
     }
     else {
         g_last_kernel = "k_blend_rows";
-        rc = dispatch_src<LaunchRows>(fmt, a, st);
+        rc = launch_rows(fmt, a, st);
     }
     if(owned) {  // in stream order: after the kernels that read it
         const hipError_t e_free = hipFreeAsync(owned, st);
@@ -501,10 +419,10 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
     if(out_ok && transposing && tile_ok(a, SRC_COPY)) {
         if(wants_col(a)) {
             g_last_kernel = "k_tile_col";
-            return LaunchTileCol<SRC_COPY>::run(a, st);
+            return launch_tile_col(SRC_COPY, a, st);
         }
         g_last_kernel = "k_tile";
-        return LaunchTile<SRC_COPY>::run(a, st);
+        return launch_tile(SRC_COPY, a, st);
     }
     if(out_ok && !transposing && linear_ok(a, SRC_COPY)) {
         g_last_kernel = "k_blend_linear";
@@ -512,7 +430,7 @@ int launch_rotate(const uint16_t * in, long long in_fs, uint16_t * out, long lon
     }
     if(transposing) {  // any size, any alignment
         g_last_kernel = "k_tile_any";
-        return LaunchTileAny<SRC_COPY>::run(a, st);
+        return launch_tile_any(SRC_COPY, a, st);
     }
     g_last_kernel = "k_flush_linear_any";
     const uint32_t area = (uint32_t)W * (uint32_t)H;
@@ -1162,15 +1080,15 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
             if(rc != LVGPU_OK) return rc;
             if(any) {
                 g_last_kernel = "k_tile_any(fused)";
-                rc = dispatch_src<LaunchTileAny>(b.src_format, a, st);
+                rc = launch_tile_any(b.src_format, a, st);
             }
             else if(transposing && wants_col(a)) {
                 g_last_kernel = "k_tile_col(fused)";
-                rc = dispatch_src<LaunchTileCol>(b.src_format, a, st);
+                rc = launch_tile_col(b.src_format, a, st);
             }
             else if(transposing) {
                 g_last_kernel = "k_tile(fused)";
-                rc = dispatch_src<LaunchTile>(b.src_format, a, st);
+                rc = launch_tile(b.src_format, a, st);
             }
             else {
                 g_last_kernel = "k_blend_linear(fused)";

@@ -1209,7 +1209,8 @@ __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t
 // of seg_px pixels of frame f in scan order, 1024 pixels at a time, and stops at the first piece that holds a
 // non-black pixel: for almost every frame that is the first piece of segment 0, so the pass reads a few KB per frame.
 // One atomicMin per block that found something (first_nb[] starts at 0xFFFFFFFF = "none").
-__global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, long long dst_fs, int dst_stride, int w, int h,
+// (The kernels that are not templates are static: this header is included by several translation units.)
+static __global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, long long dst_fs, int dst_stride, int w, int h,
                                                         int n_frames, uint32_t seg_px, uint32_t * first_nb)
 {
     __shared__ uint32_t wave_best[4];
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_first_nonblack(const uint16_t * dst, lo
 // buffers are not 16-byte aligned (466x466 panels; frames packed at odd strides).  A frame's pixels are contiguous, so
 // group g of the output is pixels 8g..8g+7 of the input or their mirror image: 8 pixels per lane with under-aligned
 // 16-byte accesses; the last, short group of a frame moves pixel by pixel.
-__global__ __launch_bounds__(256) void k_flush_linear_any(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
+static __global__ __launch_bounds__(256) void k_flush_linear_any(const uint16_t * in, long long in_fs, uint16_t * out, long long out_fs,
                                                           uint32_t area, int rot, int swap_out, int n_frames)
 {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
@@ -1280,14 +1281,14 @@ __global__ __launch_bounds__(256) void k_flush_linear_any(const uint16_t * in, l
 // ---------------------------------------------------------------------------------------------------------------
 // colour conversion, split, copy, synthetic data, checksum
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap)
+static __global__ void k_from_rgb888(const uint32_t * in, uint16_t * out, size_t n, int swap)
 {
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         uint32_t c = px_from_argb8888(in[i]);
         out[i] = (uint16_t)(swap ? px_swap16(c) : c);
     }
 }
-__global__ void k_to32(const uint16_t * in, uint32_t * out, size_t n, int swap)
+static __global__ void k_to32(const uint16_t * in, uint32_t * out, size_t n, int swap)
 {
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         uint32_t c = in[i];
@@ -1297,7 +1298,7 @@ __global__ void k_to32(const uint16_t * in, uint32_t * out, size_t n, int swap)
 // convert_cb + recolor: fmt SRC_RGB565 copies the colour (alpha 255, or 0 where it equals the chroma key); rc.opa_inv
 // == 255 means "no recolor" (lv_color_mix_premult with nothing premultiplied and mix 255 would not be the identity
 // in general, so it is skipped as the reference skips it).
-__global__ void k_image_convert(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap, int keyed,
+static __global__ void k_image_convert(const void * src, int fmt, uint16_t * color, uint8_t * alpha, size_t n, int swap, int keyed,
                                 uint32_t key, int recolor, PremultFill rc)
 {
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -1329,7 +1330,7 @@ __global__ void k_image_convert(const void * src, int fmt, uint16_t * color, uin
 // Vector forms of the conversions above: a lane converts 8 consecutive pixels with 16-byte accesses (alpha: 8 bytes);
 // n8 = number of 8-pixel groups, all pointers aligned to their access size.  The blocks of an XCD take one contiguous
 // eighth of the buffer.  What is left over (fewer than 8 pixels, or buffers that are not aligned) takes the scalar kernels.
-__global__ __launch_bounds__(256) void k_from_rgb888_v(const uint4 * in, uint4 * out, size_t n8, int swap)
+static __global__ __launch_bounds__(256) void k_from_rgb888_v(const uint4 * in, uint4 * out, size_t n8, int swap)
 {
     for(size_t g = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
         const uint4 a = in[2 * g], b = in[2 * g + 1];
@@ -1340,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_from_rgb888_v(const uint4 * in, uint4 *
         out[g] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
-__global__ __launch_bounds__(256) void k_to32_v(const uint4 * in, uint4 * out, size_t n8, int swap)
+static __global__ __launch_bounds__(256) void k_to32_v(const uint4 * in, uint4 * out, size_t n8, int swap)
 {
     for(size_t g = xcd_remap(blockIdx.x, gridDim.x) * (size_t)256 + threadIdx.x; g < n8; g += (size_t)gridDim.x * 256) {
         const uint4 v = in[g];
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_image_convert_v(const void * src, uint4
 // lv_color_fill: a lane stores one 16-byte-aligned word of 8 pixels (write-once stores); the words at the two ends of
 // a buffer that does not start or end on a 16-byte boundary are stored pixel by pixel, inside the buffer only.
 // n_words counts the aligned words the buffer touches, first_px = pixels of the first word that lie before buf.
-__global__ __launch_bounds__(256) void k_fill16(uint16_t * word0, uint32_t first_px, uint16_t color, size_t n, size_t n_words)
+static __global__ __launch_bounds__(256) void k_fill16(uint16_t * word0, uint32_t first_px, uint16_t color, size_t n, size_t n_words)
 {
     const uint32_t c2 = (uint32_t)color * 0x00010001u;
     const uint4 v = make_uint4(c2, c2, c2, c2);
@@ -1408,7 +1409,7 @@ __device__ __forceinline__ uint32_t ui_alpha(uint64_t h)
     if(t == 1) return 255;
     return 1u + ((uint32_t)(h >> 32) & 0xFFFFu) % 254u;
 }
-__global__ void k_synth(void * out, int kind, uint64_t seed, uint64_t first, size_t n)
+static __global__ void k_synth(void * out, int kind, uint64_t seed, uint64_t first, size_t n)
 {
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         uint64_t h = fin64(seed + (first + i + 1) * 0x9E3779B97F4A7C15ULL);
@@ -1421,7 +1422,7 @@ __global__ void k_synth(void * out, int kind, uint64_t seed, uint64_t first, siz
         }
     }
 }
-__global__ void k_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, unsigned long long * sum)
+static __global__ void k_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, unsigned long long * sum)
 {
     uint64_t s = 0;
     for(size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -1440,7 +1441,7 @@ __global__ void k_checksum(const void * in, int elem_bytes, uint64_t first, size
 }
 
 // one count per workgroup, binned by the XCD it ran on (HW_REG_XCC_ID, bits 3:0)
-__global__ void k_xcc_census(uint32_t * counts8)
+static __global__ void k_xcc_census(uint32_t * counts8)
 {
     if(threadIdx.x == 0) {
         uint32_t id;

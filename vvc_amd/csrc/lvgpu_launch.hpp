@@ -1,0 +1,46 @@
+// lvgpu_launch.hpp -- what the translation units of liblvgpu.so share on the host side.  The kernels are spread
+// over three of them so that they compile side by side: lvgpu.hip (C ABI, argument resolution, the linear, ARGB8565,
+// display-list and conversion kernels), lvgpu_tiles.hip (k_tile, k_tile_col, k_tile_any) and lvgpu_rows.hip
+// (k_blend_rows).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lvgpu.h"
+#include "lvgpu_kernels.hpp"
+
+namespace lvgpu {
+
+// records the calling thread's error text (lvgpu_last_error) and returns code
+int host_fail(int code, const char * text);
+
+// Dynamic LDS to ask for so that fewer workgroups share a CU (0 on a stream confined to some of the CUs, or with
+// LVGPU_NO_RESIDENCY_CAP in the environment); the values sit on measured plateaus, see their uses.
+constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024;
+uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes);
+
+// One launch each; fmt is a SrcFmt (SRC_COPY: rotation alone).  Shapes are checked by the callers (tile_ok, ...).
+int launch_tile(int fmt, const BlendArgs & a, hipStream_t st);
+int launch_tile_col(int fmt, const BlendArgs & a, hipStream_t st);
+int launch_tile_any(int fmt, const BlendArgs & a, hipStream_t st);
+int launch_rows(int fmt, const BlendArgs & a, hipStream_t st);
+
+#define LVGPU_LAUNCH_TRY(expr)                                                                                      \
+    do {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                     \
+        if(e_ != hipSuccess) return host_fail(LVGPU_ERR_HIP, (std::string(#expr ": ") + hipGetErrorString(e_)).c_str()); \
+    } while(0)
+
+template <template <int> class L, typename... Args>
+int dispatch_src(int fmt, Args &&... args)
+{
+    switch(fmt) {
+        case SRC_FILL: return L<SRC_FILL>::run(args...);
+        case SRC_RGB565: return L<SRC_RGB565>::run(args...);
+        case SRC_ARGB8888: return L<SRC_ARGB8888>::run(args...);
+        case SRC_RGBA8888: return L<SRC_RGBA8888>::run(args...);
+        case SRC_ARGB8565: return L<SRC_ARGB8565>::run(args...);
+        default: return L<SRC_COPY>::run(args...);
+    }
+}
+
+}  // namespace lvgpu
