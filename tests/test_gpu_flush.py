@@ -7,17 +7,22 @@ from util import rand_mask, to_dev, to_np
 pytestmark = pytest.mark.gpu
 
 
-def quarter_turn_kernel(W, H):
-    """Heights on the 32-px grid: one tile per wavefront; off it, a column of tiles per workgroup (panel rows of up to
-    256 pixels are one run of the any-size kernel's workgroup and go there); sizes off the 8-pixel grid: any-size."""
+def quarter_turn_kernel(W, H, fused=False):
+    """Heights on the 32-px grid: one tile per wavefront.  Off it, kernels that write long panel-row runs: the
+    any-size kernel (workgroups sized to the height) up to 256 rows, and for the rotation alone also up to 384 and from
+    513 to 1536 rows; otherwise a 512-row column of tiles per workgroup.  Sizes off the 8-pixel grid: any-size."""
     if W % 8 or H % 8 or (H % 32 and H <= 256):
+        return "k_tile_any"
+    if H % 32 and not fused and (H <= 384 or 512 < H <= 1536):
         return "k_tile_any"
     return "k_tile_col" if H % 32 else "k_tile"
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3),
-                                   (96, 200), (64, 40), (200, 344), (136, 72), (8, 8), (240, 135), (135, 240), (65, 129)])
+                                   (96, 200), (64, 40), (200, 344), (136, 72), (8, 8), (240, 135), (135, 240), (65, 129),
+                                   # any-size kernel with 5, 6, 4 + 4, 5 + 5 and 6 + 6 + 6 wavefronts; the column kernel above
+                                   (482, 320), (481, 321), (40, 328), (33, 466), (24, 600), (16, 1080), (8, 1544)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -119,7 +124,7 @@ def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
         dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
                            mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
         out = gpu.blend_flush(gpu.DrawCtx(d), dsc, rot)
-        assert gpu.last_kernel() == quarter_turn_kernel(W, H) + "(fused)"
+        assert gpu.last_kernel() == quarter_turn_kernel(W, H, fused=True) + "(fused)"
         assert np.array_equal(to_np(d, np.uint16), exp_dst)
         got = to_np(out, np.uint16).reshape(N, -1)
         for f in range(N):
@@ -167,7 +172,8 @@ def test_rotate_against_lvgl_own_sw_rotate(gpu, swap):
 
 
 @pytest.mark.parametrize("rot", [1, 3])
-@pytest.mark.parametrize("shape", [(100, 37), (135, 240), (65, 129), (7, 3), (1, 1), (466, 30), (9, 513), (64, 520)])
+@pytest.mark.parametrize("shape", [(100, 37), (135, 240), (65, 129), (7, 3), (1, 1), (466, 30), (9, 513), (64, 520),
+                                   (481, 321), (33, 466), (172, 320)])
 def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
     """A quarter-turn flush of frames off the 8-pixel grid is still one pass with the blend (k_tile_any): every source
     kind, both byte orders, the translucent fill with its scan-order rule, frames whose stride leaves every frame at
@@ -202,7 +208,7 @@ def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
             dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
                                mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None)
             out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
-            assert gpu.last_kernel() == quarter_turn_kernel(W, H) + "(fused)"
+            assert gpu.last_kernel() == quarter_turn_kernel(W, H, fused=True) + "(fused)"
             assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
             got = to_np(out, np.uint16).reshape(N, -1)
             for f in range(N):

@@ -345,10 +345,16 @@ bool linear_ok(const BlendArgs & a, int fmt)
 // ... and additionally as whole W x H frames for the tile kernel (row starts stay 16-byte aligned).
 bool tile_ok(const BlendArgs & a, int fmt)
 {
-    // a panel row of up to 256 pixels that does not end on a 64-byte boundary is one run of k_tile_any's four-wave
-    // workgroup: ahead of k_tile_col there, whose eight waves would be half idle (320x200: 72 against 65 % rotating,
-    // 68 against 63 % fused); taller frames stay with k_tile_col (480x272 ... 3840x2160: 1 to 10 points ahead)
-    if((a.h % 32) != 0 && a.h <= TILE * ANY_WPB) return false;
+    // Heights off the 32-pixel grid: which of the two kernels that write long panel-row runs is ahead was measured.
+    // With the blend fused in, k_tile_any up to 256 rows (one run per panel row: 320x200 68 against 63 % of peak), the
+    // eight-wave k_tile_col above (480x328 63 against 53 %, 1080p 64 against 56 %).  The rotation alone stays with
+    // k_tile_any, whose workgroups are sized to the height, wherever k_tile_col's 512-row workgroups would be idle for
+    // a good part: up to 384 rows (480x272 68 against 63 %) and from 513 to 1536 (1024x600 62 against 54 %, 1080p 64
+    // against 61 %); from 385 to 512 rows and on 4K canvases k_tile_col is level or ahead (464x464 66 against 64 %).
+    if((a.h % 32) != 0) {
+        if(a.h <= 256) return false;
+        if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 512 && a.h <= 1536))) return false;
+    }
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
 

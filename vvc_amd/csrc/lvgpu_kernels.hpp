@@ -772,26 +772,29 @@ __device__ __forceinline__ void store_group_masked_any(uint16_t * p, uint4 r, ui
     }
 }
 
-// Four wavefronts per workgroup (512-byte runs): measured against 2, 3, 6 and 8 on 240x135, 135x240, 320x172 and 466x466
-// frames, 4 is ahead everywhere (fused 49-68 % of peak against 30-47 % with 8).
-constexpr int ANY_WPB = 4;
+// The number of wavefronts per workgroup (wpb, 1..8) is chosen at launch so that a workgroup's 64 * wpb rows fit the
+// frame height with as few idle wavefronts as possible; up to 512 rows one workgroup takes a column of tiles whole
+// and writes complete panel rows, which follow each other in memory.  The exchange area is 8 KB of dynamic LDS per
+// wavefront: [panel row of the region 0..63][chunk of the run 0..8*wpb-1], swizzled.
+constexpr int ANY_WPB_MAX = 8, ANY_WPB_MAX_BLEND = 4;  // with the blend fused in, larger workgroups only lose
 template <int SRC>
-__global__ __launch_bounds__(64 * ANY_WPB) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, uint32_t n_blocks)
+__global__ __launch_bounds__(64 * (SRC == SRC_COPY ? ANY_WPB_MAX : ANY_WPB_MAX_BLEND)) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
 {
-    __shared__ uint4 lds[64 * 8 * ANY_WPB];   // [panel row of the block 0..63][chunk of the run 0..8*ANY_WPB-1], swizzled
+    extern __shared__ uint4 lds[];
+    const int RUN = 8 * wpb;               // 16-byte chunks per output run
+    const int TH = TILE * wpb;             // rows of the region
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);  // gridDim.x == n_blocks
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t bpf = tiles_x * cols_y;
     const uint32_t f = blk / bpf;
     const uint32_t t = blk - f * bpf;
     const uint32_t tx = t / cols_y, cy = t - tx * cols_y;   // the blocks of a column follow each other (see k_tile_col)
     constexpr bool BLEND = SRC != SRC_COPY;
-    constexpr int RUN = 8 * ANY_WPB;
     const bool r90 = a.rot == 1;
 
     const int bx = lane & 7, by = lane >> 3;
-    const int Y0 = (int)cy * TILE * ANY_WPB;
+    const int Y0 = (int)cy * TH;
     const int x0 = tx * TILE + bx * 8, y0 = Y0 + wave * TILE + by * 8;
     if(x0 < W && y0 < H) {
         uint16_t * dst = a.dst + (long long)f * a.dst_fs;
@@ -811,8 +814,13 @@ __global__ __launch_bounds__(64 * ANY_WPB) void k_tile_any(BlendArgs a, int W, i
             mk[i] = make_uint2(0, 0);
             if(y0 + i >= H) continue;
             const size_t p = (size_t)(y0 + i) * a.dst_stride + x0;
+            // A block that sticks out of the frame on the right is still loaded with wide accesses wherever another row
+            // follows in the same frame: what they read beyond the row's end is the start of that row (x0 + 8 <= W + 7
+            // < 2 W, and rows lie at least W pixels apart in all three buffers); only the frame's last row, and frames
+            // narrower than a group, are gathered pixel by pixel.  The surplus pixels are never stored.
+            const bool wide = full_x || (W >= 8 && y0 + i + 1 < H);
             if(fast != FAST_OPAQUE) {
-                if(full_x) d[i] = load16_any(dst + p);
+                if(wide) d[i] = load16_any(dst + p);
                 else {
                     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -824,12 +832,12 @@ __global__ __launch_bounds__(64 * ANY_WPB) void k_tile_any(BlendArgs a, int W, i
             if(BLEND) {
                 if(SRC != SRC_FILL) {
                     const long long sp = src_px0 + (long long)(y0 + i) * a.src_stride + x0;
-                    if(full_x) load_src_unaligned<SRC>(a.src, sp, sw[i]);
+                    if(wide) load_src_unaligned<SRC>(a.src, sp, sw[i]);
                     else load_src_guarded<SRC>(a.src, sp, 0, nx, sw[i]);
                 }
                 if(mask) {
                     const uint8_t * mp = mask + (size_t)(y0 + i) * a.mask_stride + x0;
-                    if(full_x) {
+                    if(wide) {
                         const u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(mp);
                         mk[i] = make_uint2(v.x, v.y);
                     }
@@ -874,11 +882,13 @@ __global__ __launch_bounds__(64 * ANY_WPB) void k_tile_any(BlendArgs a, int W, i
     __syncthreads();
     if(a.out) {
         uint16_t * out = a.out + (long long)f * a.out_fs;
-        const int run0 = r90 ? H - Y0 - TILE * ANY_WPB : Y0;   // first pixel of the run within its panel row (may be < 0)
+        const int run0 = r90 ? H - Y0 - TH : Y0;   // first pixel of the run within its panel row (may be < 0)
+        // chunk q = (k * wpb + wave) * 64 + lane of the region's 64 x RUN chunks lies in panel row q / RUN = 8 k + xl0
+        const int u = wave * 8 + (lane >> 3), xl0 = u / wpb;
+        const int qc = (u - xl0 * wpb) * 8 + (lane & 7);
 #pragma unroll
         for(int k = 0; k < 8; k++) {
-            const int q = (k * ANY_WPB + wave) * 64 + lane;
-            const int xl = q / RUN, qc = q - xl * RUN;
+            const int xl = k * 8 + xl0;
             const int X = tx * TILE + xl;
             const int px = run0 + qc * 8;
             if(X >= W || px + 8 <= 0 || px >= H) continue;
