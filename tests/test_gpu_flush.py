@@ -131,6 +131,37 @@ def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
             assert np.array_equal(got[f], oracle.flush_frame(exp_dst[f], W, H, rot, 0)), (fmt, f)
 
 
+@pytest.mark.parametrize("rot", [1, 3])
+@pytest.mark.parametrize("shape", [(200, 96), (504, 64), (512, 128), (8, 32), (136, 160), (320, 480), (520, 64)])
+def test_blend_flush_fused_band_kernel(gpu, oracle, rot, shape):
+    """Masked fills and maps of frames up to 512 px wide (heights on the 32-px grid) take the band kernel: whole rows
+    through LDS.  Both byte orders, opacities on both sides of the thresholds, a leading black region."""
+    W, H = shape
+    N = 3
+    rng = np.random.default_rng(W * 3 + H + rot)
+    area = (0, 0, W - 1, H - 1)
+    for swap in (1, 0):
+        for fmt, opa in ((1, 255), (1, 200), (0, 255), (0, 180)):
+            dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            dst[1].reshape(-1)[: (W * H) // 2] = 0
+            color = int(rng.integers(0, 65536))
+            src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16) if fmt == 1 else None
+            mask = rand_mask(rng, (N, H, W))
+            exp = dst.copy()
+            for f in range(N):
+                oracle.blend(exp[f], area, area, area, src=None if src is None else src[f], color=color, mask=mask[f],
+                             opa=opa, swap=swap)
+            d = to_dev(dst)
+            dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color, mask_buf=to_dev(mask),
+                               opa=opa)
+            out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
+            assert gpu.last_kernel() == ("k_band(fused)" if W <= 512 else "k_tile(fused)")
+            assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
+            got = to_np(out, np.uint16).reshape(N, -1)
+            for f in range(N):
+                assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 1 - swap)), (swap, fmt, opa, f)
+
+
 def test_blend_flush_unfused_shapes(gpu, oracle):
     """Partial blend area or odd geometry: same result through blend + rotate launches."""
     rng = np.random.default_rng(5)

@@ -1092,6 +1092,11 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
                 g_last_kernel = "k_tile_col(fused)";
                 rc = launch_tile_col(b.src_format, a, st);
             }
+            else if(transposing && a.mask && a.w <= BAND_MAX_W && (b.src_format == SRC_FILL || b.src_format == SRC_RGB565)) {
+                // a mask plane beside the pixels: bands of whole rows read it in whole lines (see k_band)
+                g_last_kernel = "k_band(fused)";
+                rc = launch_band(b.src_format, a, st);
+            }
             else if(transposing) {
                 g_last_kernel = "k_tile(fused)";
                 rc = launch_tile(b.src_format, a, st);

@@ -27,6 +27,19 @@ struct LaunchTile {
     }
 };
 template <int SRC>
+int launch_band_src(const BlendArgs & a, hipStream_t st)
+{
+    const int W = a.w, H = a.h;
+    const uint32_t bands = (H + BAND_H - 1) / BAND_H;
+    const uint64_t n_blocks = (uint64_t)bands * a.n_frames;
+    if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
+    // one workgroup per CU for the plain-mix case (RGB565 + A8 image: 68.0 % of peak uncapped, 69.3 % capped)
+    const uint32_t pad = fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, BAND_PAD_LDS) : 0;
+    hipLaunchKernelGGL(k_band<SRC>, dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
+    LVGPU_LAUNCH_TRY(hipGetLastError());
+    return LVGPU_OK;
+}
+template <int SRC>
 struct LaunchTileCol {
     static int run(const BlendArgs & a, hipStream_t st)
     {
@@ -75,6 +88,10 @@ struct LaunchTileAny {
 
 int launch_tile(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTile>(fmt, a, st); }
 int launch_tile_col(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTileCol>(fmt, a, st); }
+int launch_band(int fmt, const BlendArgs & a, hipStream_t st)
+{
+    return fmt == SRC_FILL ? launch_band_src<SRC_FILL>(a, st) : launch_band_src<SRC_RGB565>(a, st);
+}
 int launch_tile_any(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTileAny>(fmt, a, st); }
 
 }  // namespace lvgpu
