@@ -134,8 +134,8 @@ def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
 @pytest.mark.parametrize("rot", [1, 3])
 @pytest.mark.parametrize("shape", [(200, 96), (504, 64), (512, 128), (8, 32), (136, 160), (320, 480), (520, 64)])
 def test_blend_flush_fused_band_kernel(gpu, oracle, rot, shape):
-    """Masked fills and maps of frames up to 512 px wide (heights on the 32-px grid) take the band kernel: whole rows
-    through LDS.  Both byte orders, opacities on both sides of the thresholds, a leading black region."""
+    """Masked fills and maps at full opacity of frames up to 512 px wide (heights on the 32-px grid) take the band
+    kernel: whole rows through LDS.  Both byte orders, opacities on both sides of the thresholds, a leading black region."""
     W, H = shape
     N = 3
     rng = np.random.default_rng(W * 3 + H + rot)
@@ -155,7 +155,8 @@ def test_blend_flush_fused_band_kernel(gpu, oracle, rot, shape):
             dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color, mask_buf=to_dev(mask),
                                opa=opa)
             out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
-            assert gpu.last_kernel() == ("k_band(fused)" if W <= 512 else "k_tile(fused)")
+            # the band kernel takes the plain mix (opacity at or above the threshold); everything else stays with the tiles
+            assert gpu.last_kernel() == ("k_band(fused)" if W <= 512 and opa == 255 else "k_tile(fused)")
             assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
             got = to_np(out, np.uint16).reshape(N, -1)
             for f in range(N):

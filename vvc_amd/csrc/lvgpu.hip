@@ -1092,8 +1092,10 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
                 g_last_kernel = "k_tile_col(fused)";
                 rc = launch_tile_col(b.src_format, a, st);
             }
-            else if(transposing && a.mask && a.w <= BAND_MAX_W && (b.src_format == SRC_FILL || b.src_format == SRC_RGB565)) {
-                // a mask plane beside the pixels: bands of whole rows read it in whole lines (see k_band)
+            else if(transposing && a.w <= BAND_MAX_W && a.mask && a.opa_mode == OM_MASK && a.blend_fn == BF_NORMAL &&
+                    (b.src_format == SRC_FILL || b.src_format == SRC_RGB565)) {
+                // a mask plane beside the pixels, mixed at full opacity: bands of whole rows read it in whole lines
+                // (see k_band; with an opacity below the threshold or a blend mode the tile kernel is 10 points ahead)
                 g_last_kernel = "k_band(fused)";
                 rc = launch_band(b.src_format, a, st);
             }

@@ -581,8 +581,11 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
 // comes out as 8-pixel pieces of panel rows, 8 lanes side by side = 128 bytes of one panel row.
 // Measured against k_tile on 4096 frames of 480x320: level for the ARGB8888 image (70.0 against 70.2 % of the HBM
 // peak) and for the rotation alone (74.2 against 74.5 %), ahead where an A8 mask plane is read (RGB565 + A8 image
-// 69.3 against 66.1 %: a tile's mask rows are half lines) -- so it is launched for masked fills and maps only.
-// Bands of 32 rows (64-byte pieces of panel rows) reach 65 %, sixteen waves per band the same as eight.
+// 69.5 against 66.1 %, masked fill 65.9 against 63.5 %: a tile's mask rows are half lines) -- as long as the blend is
+// the plain mix: at opacity 200, which takes the per-pixel opacity arithmetic, its eight-wave workgroups fall to
+// 53.6 % where k_tile holds 63.4 %, and an ARGB8565 image runs at 62.9 against 68.2 %.  So it is launched for masked
+// fills and maps at full opacity only.  Bands of 32 rows (64-byte pieces of panel rows) reach 65 %, sixteen waves per
+// band the same as eight.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BAND_H = 64, BAND_WAVES = 8, BAND_MAX_W = 512;
 template <int SRC>

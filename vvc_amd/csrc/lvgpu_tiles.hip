@@ -33,8 +33,8 @@ int launch_band_src(const BlendArgs & a, hipStream_t st)
     const uint32_t bands = (H + BAND_H - 1) / BAND_H;
     const uint64_t n_blocks = (uint64_t)bands * a.n_frames;
     if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
-    // one workgroup per CU for the plain-mix case (RGB565 + A8 image: 68.0 % of peak uncapped, 69.3 % capped)
-    const uint32_t pad = fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, BAND_PAD_LDS) : 0;
+    // one workgroup per CU (RGB565 + A8 image: 68.0 % of peak uncapped, 69.3 % capped); the callers send the plain-mix case only
+    const uint32_t pad = residency_pad(st, BAND_PAD_LDS);
     hipLaunchKernelGGL(k_band<SRC>, dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
     LVGPU_LAUNCH_TRY(hipGetLastError());
     return LVGPU_OK;
@@ -90,7 +90,10 @@ int launch_tile(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_
 int launch_tile_col(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTileCol>(fmt, a, st); }
 int launch_band(int fmt, const BlendArgs & a, hipStream_t st)
 {
-    return fmt == SRC_FILL ? launch_band_src<SRC_FILL>(a, st) : launch_band_src<SRC_RGB565>(a, st);
+    switch(fmt) {
+        case SRC_FILL: return launch_band_src<SRC_FILL>(a, st);
+        default: return launch_band_src<SRC_RGB565>(a, st);
+    }
 }
 int launch_tile_any(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTileAny>(fmt, a, st); }
 
