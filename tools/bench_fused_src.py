@@ -1,4 +1,6 @@
 """The fused blend + quarter-turn flush per source kind on 4096 frames of 480x320 (HIP events, median of 9 launches).
+With LVGPU_NO_BAND=1 in the environment the masked cases stay on the tile kernel: run both ways to compare k_band
+with k_tile on the machine at hand.
     python3 tools/bench_fused_src.py"""
 import os
 import sys

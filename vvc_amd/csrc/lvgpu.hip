@@ -288,7 +288,7 @@ struct LaunchLinear {
         if(blocks > 0x7FFFFFFFull) return fail(LVGPU_ERR_ARG, "batch too large for one launch");
         const int fast = fast_path<SRC>(a);
         uint32_t pad = 0;
-        if(fast == FAST_MIX) pad = residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS);
+        if(fast_is_mix(fast)) pad = residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS);
         // FAST_OPAQUE (opaque fill / map: write-once stores that bypass the L2) is fastest uncapped: 88 % / 77 % of peak
         hipLaunchKernelGGL(k_blend_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());
@@ -323,6 +323,14 @@ struct LaunchArgbLinear {
 // Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
 // the tile kernel's 128-byte output runs degrade; the column kernel writes 1-KB runs.
 inline bool wants_col(const BlendArgs & a) { return (a.h % 32) != 0; }
+
+// LVGPU_NO_BAND in the environment keeps masked fused launches on the tile kernel: tools/bench_fused_src.py uses it to
+// compare the two on the machine at hand.
+inline bool band_disabled()
+{
+    static const bool off = getenv("LVGPU_NO_BAND") != nullptr;
+    return off;
+}
 
 // Can the clipped area of every frame be walked as one contiguous, 16-byte aligned run of 8-pixel groups?
 bool linear_ok(const BlendArgs & a, int fmt)
@@ -1093,7 +1101,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
                 rc = launch_tile_col(b.src_format, a, st);
             }
             else if(transposing && a.w <= BAND_MAX_W && a.mask && a.opa_mode == OM_MASK && a.blend_fn == BF_NORMAL &&
-                    (b.src_format == SRC_FILL || b.src_format == SRC_RGB565)) {
+                    (b.src_format == SRC_FILL || b.src_format == SRC_RGB565) && !band_disabled()) {
                 // a mask plane beside the pixels, mixed at full opacity: bands of whole rows read it in whole lines
                 // (see k_band; with an opacity below the threshold or a blend mode the tile kernel is 10 points ahead)
                 g_last_kernel = "k_band(fused)";

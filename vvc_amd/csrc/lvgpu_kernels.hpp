@@ -249,7 +249,11 @@ __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_
 //                lv_color_fill / lv_memcpy per row): the destination is only written, so it is not loaded either.
 //   FAST_PREMULT fill_normal without mask below LV_OPA_MAX (:261-287): the premultiplied formula in packed 16-bit
 //                arithmetic; per pixel it is bound by instruction issue (29 -> 15 lane instructions per pixel).
-enum FastPath : int { FAST_NONE = 0, FAST_MIX = 1, FAST_OPAQUE = 2, FAST_PREMULT = 3 };
+//   FAST_MIX_CONST / _FILL_OPA / _MAP_OPA: the other three ways the normal blend function derives a pixel's opacity
+//                (map_normal without mask below LV_OPA_MAX :662-670; masked fill :346-373 and masked map :720-732 below
+//                the threshold): still nothing but lv_color_mix, with the opacity mode fixed for the launch.
+enum FastPath : int { FAST_NONE = 0, FAST_MIX = 1, FAST_OPAQUE = 2, FAST_PREMULT = 3, FAST_MIX_CONST = 4, FAST_MIX_FILL_OPA = 5,
+                      FAST_MIX_MAP_OPA = 6 };
 template <int SRC, class A>
 __host__ __device__ __forceinline__ int fast_path(const A & a)
 {
@@ -258,13 +262,24 @@ __host__ __device__ __forceinline__ int fast_path(const A & a)
     if(a.opa_mode == OM_MASK) return FAST_MIX;
     if(a.opa_mode == OM_FILL_PREMULT) return SRC == SRC_FILL ? FAST_PREMULT : FAST_NONE;
     if(a.opa_mode == OM_CONST && a.opa == 255u && !own_alpha) return FAST_OPAQUE;
+    if(a.opa_mode == OM_CONST) return FAST_MIX_CONST;
+    if(a.opa_mode == OM_FILL_MASK_OPA) return FAST_MIX_FILL_OPA;
+    if(a.opa_mode == OM_MAP_MASK_OPA) return FAST_MIX_MAP_OPA;
     return FAST_NONE;
+}
+// the launch is nothing but lv_color_mix at an opacity derived one way for all pixels
+__host__ __device__ __forceinline__ bool fast_is_mix(int fast)
+{
+    return fast == FAST_MIX || fast == FAST_MIX_CONST || fast == FAST_MIX_FILL_OPA || fast == FAST_MIX_MAP_OPA;
 }
 template <int SRC, class A>
 __device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0,
                                                uint32_t fnb)
 {
     if(fast == FAST_MIX) return blend_group_mix<SRC, OM_MASK>(a, d, sw, mk);
+    if(fast == FAST_MIX_CONST) return blend_group_mix<SRC, OM_CONST>(a, d, sw, mk);
+    if(fast == FAST_MIX_FILL_OPA) return blend_group_mix<SRC, OM_FILL_MASK_OPA>(a, d, sw, mk);
+    if(fast == FAST_MIX_MAP_OPA) return blend_group_mix<SRC, OM_MAP_MASK_OPA>(a, d, sw, mk);
     if(fast == FAST_OPAQUE) return blend_group_s<SRC, OM_OPAQUE, false>(a, d, sw, mk, scan0, fnb);
     if(fast == FAST_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     return blend_group<SRC>(a, d, sw, mk, scan0, fnb);

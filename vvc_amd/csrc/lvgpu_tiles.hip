@@ -19,7 +19,7 @@ struct LaunchTile {
         const uint64_t n_tiles = (uint64_t)tpf * a.n_frames;
         if(n_tiles > 0xFFFFFFF0ull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
         const uint32_t pad = SRC == SRC_COPY ? residency_pad(st, TILE_PAD_LDS_COPY)
-                                             : (fast_path<SRC>(a) == FAST_MIX ? residency_pad(st, TILE_PAD_LDS) : 0);
+                                             : (fast_is_mix(fast_path<SRC>(a)) ? residency_pad(st, TILE_PAD_LDS) : 0);
         hipLaunchKernelGGL(k_tile<SRC>, dim3((uint32_t)((n_tiles + TILE_WPB - 1) / TILE_WPB)), dim3(64 * TILE_WPB), pad, st, a, W, H,
                            tiles_x, tiles_y, tpf, (uint32_t)n_tiles);
         LVGPU_LAUNCH_TRY(hipGetLastError());
