@@ -11,7 +11,11 @@
  * (hipExtStreamGetCUMask): on a stream that owns the whole device they cap how many workgroups share a CU, which
  * raises the HBM rate; a stream confined to some CUs keeps the default.  Results do not depend on it.  The cap is a
  * tuning measured on MI355X under ROCm 7.2; setting LVGPU_NO_RESIDENCY_CAP in the environment (read once, at the first
- * launch) disables it, and tools/check_residency.py compares both settings on the machine at hand.
+ * launch) disables it, and tools/check_residency.py compares both settings on the machine at hand.  Two more
+ * environment switches exist for measuring, none of them changes a result: LVGPU_NO_BAND (read once) keeps the fused
+ * quarter-turn flush of masked fills and maps on the tile kernel instead of the band kernel, LVGPU_ANY_WPB=1..8 (read
+ * at every launch) fixes the workgroup size of the any-size quarter-turn kernel (tools/bench_fused_src.py,
+ * tools/bench_any_shapes.sh).
  *
  * Pixel vocabulary (libraries/lvgl/src/misc/lv_color.h:208-222): a pixel is lv_color16_t, 2 bytes.
  *   color_16_swap = 1 : LV_COLOR_16_SWAP 1, memory bytes {RRRRRGGG, GGGBBBBB} (big-endian RGB565 = panel wire order)
