@@ -84,6 +84,13 @@ def lib():
         raise ImportError(
             "liblvgpu.so not found at %s -- build it with `make -C vvc_amd/csrc` (hipcc, gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch brings its own copy of the HIP runtime; when it is to be used in the same process (device memory for the
+    # tests and bench.py) it has to be loaded first, or the process ends up with two runtimes of which the second sees
+    # no device.  Without torch installed the library is loaded on its own.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
     sig = {
