@@ -7,7 +7,9 @@
 //   k_tile         : blend and/or 90/270-degree rotation; a wave owns a 64x64-pixel tile, each lane an 8x8 block,
 //                    transposes it in registers and exchanges it through wave-private LDS so that both the loads
 //                    and the rotated stores are 128-byte contiguous per 8 lanes
-//   k_blend_rows   : blend over any rectangle/alignment: 16-byte-aligned destination groups, scalar row edges
+//   k_tile_col     : the same for heights off the 32-pixel grid: a column of tiles per workgroup, 1-KB output runs
+//   k_band         : the same fused with masked fills and maps: bands of whole rows, linear loads, the turn in LDS
+//   k_blend_rows   : blend over any rectangle/alignment: 16-byte-aligned destination groups, row edges pixel-exact
 //   k_tile_any / k_flush_linear_any : the flush for frames of any size and alignment
 #pragma once
 #include "lvgpu_px.hpp"
