@@ -6,6 +6,10 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
                            map_normal with per-pixel alpha) fused with the 90-degree flush rotation into the 320x480
                            panel image: 4 B + 2 B read, 2 B + 2 B written per pixel = 10 algorithmic bytes/px.
                            With --swap 0 the buffers are LV_COLOR_16_SWAP 0 and the flush byte-swaps into wire order.
+    blend_flush_nowb       blend_flush for a display under full_refresh (the reference's configuration, src/lv_port.c:241:
+                           LVGL redraws the whole buffer on every refresh, so the blended draw buffer is dead once it has
+                           been flushed): LVGPU_BLEND_FLAG_DISCARD_DST skips the write-back of the draw buffer, 4 B + 2 B
+                           read, 2 B written per pixel = 8 algorithmic bytes/px.  Reported beside the default, never instead.
     blend / rotate         the blend alone (8 B/px) / the flush rotation alone (4 B/px)
     blend_rgb565a8, blend_flush_rgb565a8   the same with a colour plane + A8 plane source (7 / 9 B/px)
     blend_flush_4k         blend_flush on 3840x2160 canvases (64 frames per GPU by default)
@@ -24,7 +28,13 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
                            counts what must move (draw buffer and panel image written once each, 4 B/px) -- this
                            kernel is bound by VALU issue, not by HBM.
 Frames are sharded over ranks (one process per GPU), there is no data-path collective; torch.distributed is used only
-for the barrier and the max-over-ranks time.
+for the barrier, the max-over-ranks time and the gather of the per-rank times -- over gloo on host tensors by default
+(a path without a collective should not depend on RCCL coming up on the node; LVGPU_BENCH_BACKEND=nccl selects RCCL).
+With more than one rank `value` comes from the slowest rank's HIP-event time around its timed steps (the ranks start
+together after a barrier + device synchronisation; host time across the closing barrier, which adds the barrier's own
+latency, is reported beside it as host_ms_per_step), and `efficiency_vs_1gpu` = value / (N x the one-GPU rate) is printed
+when that rate is known: from --ref-1gpu-mpx, or from the line a one-GPU run of the same workload left in
+gpurun_out/bench_1gpu_cache.json on this machine within the last six hours.
 
 `--gpus N` with N > 1 and no torchrun environment: this process starts N ranks as a child
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...`) before it touches any GPU, relays the child's
@@ -51,7 +61,8 @@ SEED_DST, SEED_SRC, SEED_MASK = 0x5EED0001, 0x5EED0002, 0x5EED0003
 MULTI_GPU_TOTAL_FRAMES = 65536  # the batch that is sharded over 2/4/8 GPUs
 # workload -> (algorithmic bytes per pixel, default logical width, height, default frames per GPU on one GPU)
 WORKLOADS = {
-    "blend_flush": (10, 480, 320, 4096), "blend": (8, 480, 320, 4096), "rotate": (4, 480, 320, 4096),
+    "blend_flush": (10, 480, 320, 4096), "blend_flush_nowb": (8, 480, 320, 4096), "blend": (8, 480, 320, 4096),
+    "rotate": (4, 480, 320, 4096),
     "blend_rgb565a8": (7, 480, 320, 4096), "blend_flush_rgb565a8": (9, 480, 320, 4096), "scene": (4, 480, 320, 4096),
     "blend_flush_4k": (10, 3840, 2160, 64), "blend_flush_466": (10, 466, 466, 2048), "flush_180_466": (4, 466, 466, 2048),
     "clipped_small": (7, 480, 320, 4096), "clipped_large": (7, 480, 320, 4096),
@@ -59,7 +70,7 @@ WORKLOADS = {
     "fill_masked": (5, 480, 320, 4096), "fill_masked_argb": (7, 480, 320, 4096),
 }
 CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300)}
-KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_tiles.hip", "lvgpu_rows.hip", "lvgpu_launch.hpp", "lvgpu_kernels.hpp", "lvgpu_list.hpp",
+KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_tiles.hip", "lvgpu_tiles_col.hip", "lvgpu_tiles_any.hip", "lvgpu_rows.hip", "lvgpu_launch.hpp", "lvgpu_kernels.hpp", "lvgpu_list.hpp",
                   "lvgpu_px.hpp")
 
 
@@ -80,7 +91,43 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eighth", action="store_true", help="skip the 32-CU (1/8 of the CUs) measurement")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--ref-1gpu-mpx", type=float, default=0.0,
+                    help="Mpx/s of the same workload on one GPU: with --gpus N > 1 the line then carries efficiency_vs_1gpu")
     return ap.parse_args(argv)
+
+
+CACHE_1GPU = os.path.join(ROOT, "gpurun_out", "bench_1gpu_cache.json")
+
+
+def cache_key(args, wl, W, H):
+    return "%s %dx%d swap%d rot%d %s" % (wl, W, H, args.swap, args.rotation, args.mask)
+
+
+def cache_1gpu_store(key, mpx, frames):
+    """Remember what one GPU did on this workload, for the efficiency figure of a later multi-GPU run here."""
+    try:
+        os.makedirs(os.path.dirname(CACHE_1GPU), exist_ok=True)
+        try:
+            with open(CACHE_1GPU) as f:
+                c = json.load(f)
+        except Exception:
+            c = {}
+        c[key] = {"Mpx_s": mpx, "frames": frames, "host": socket.gethostname(), "time": time.time()}
+        with open(CACHE_1GPU, "w") as f:
+            json.dump(c, f)
+    except Exception:
+        pass  # a read-only tree costs the later run its efficiency figure, nothing else
+
+
+def cache_1gpu_load(key, max_age_s=6 * 3600):
+    try:
+        with open(CACHE_1GPU) as f:
+            e = json.load(f).get(key)
+        if e and e.get("host") == socket.gethostname() and time.time() - e["time"] < max_age_s:
+            return float(e["Mpx_s"])
+    except Exception:
+        pass
+    return None
 
 
 def frames_for(frames_per_gpu, world, one_gpu_default):
@@ -315,7 +362,7 @@ def main(argv=None):
 
     # LVGPU_BENCH_BACKEND=gloo + LVGPU_BENCH_ONE_DEVICE=1 rehearse the multi-rank code path on a single GPU
     # (all ranks share device 0; the numbers are then meaningless, the control flow is what is exercised).
-    backend = os.environ.get("LVGPU_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("LVGPU_BENCH_BACKEND", "gloo")
     one_dev = os.environ.get("LVGPU_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
@@ -349,7 +396,7 @@ def main(argv=None):
     keep = []          # tensors the descriptors point into
 
     out = None
-    wants_out = wl in ("blend_flush", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
+    wants_out = wl in ("blend_flush", "blend_flush_nowb", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
     if wl == "flush_180_466":
         rot = 2
     if wl == "fill_masked_argb":
@@ -363,9 +410,10 @@ def main(argv=None):
         out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
 
     dsc, blist, rec = None, None, None
-    if wl in ("blend_flush", "blend", "blend_flush_4k", "blend_flush_466"):
+    if wl in ("blend_flush", "blend_flush_nowb", "blend", "blend_flush_4k", "blend_flush_466"):
         src = lvgpu.synth(argb_kind, SEED_SRC, first, (n, H, W))
-        dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
+        dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888,
+                             flags=lvgpu.FLAG_DISCARD_DST if wl == "blend_flush_nowb" else 0)
     elif wl.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
         src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
         a8 = lvgpu.synth(mask_kind, SEED_MASK, first, (n, H, W))
@@ -451,9 +499,12 @@ def main(argv=None):
     torch.cuda.synchronize()
     per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(11))
     ev_median = per_step[5]
-    own_dt = dt
+    own_ev_s = ev_ms / 1e3
     dt, ev_ms, ev_median = sharding.max_over_ranks(dist, [dt, ev_ms, ev_median])
-    per_rank_dt = sharding.gather_floats(dist, own_dt)
+    per_rank_dt = sharding.gather_floats(dist, own_ev_s)
+    host_dt = dt
+    if world > 1:
+        dt = ev_ms / 1e3  # the slowest rank's device time for its K steps; the closing barrier's latency stays out
 
     eighth = None
     copy_gbs = None
@@ -499,9 +550,11 @@ def main(argv=None):
                     "%d frames per GPU" % (wl, args.swap, " (byte-swapped into wire order)" if swap_bytes else "", W, H, rot * 90, n))
         else:
             desc = ("%s: image with per-pixel alpha over RGB565 (%s alpha), opa 255, LV_COLOR_16_SWAP %d%s, %dx%d logical, "
-                    "rotation %d, %d frames per GPU"
+                    "rotation %d, %d frames per GPU%s"
                     % (wl, args.mask, args.swap, " (flush byte-swaps into wire order)" if swap_bytes and wants_out else "",
-                       W, H, rot * 90, n))
+                       W, H, rot * 90, n,
+                       "; the blended draw buffer is NOT written back (full_refresh display, LVGPU_BLEND_FLAG_DISCARD_DST)"
+                       if wl == "blend_flush_nowb" else ""))
         res = {
             "metric": "Mpixels/sec batched 320x480 RGB565 blend+rotate; % of HBM peak at 1/8 GPU",
             "value": round(total_px / dt / 1e6, 1),
@@ -532,6 +585,16 @@ def main(argv=None):
             res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
         if world > 1:
             res["per_rank_Mpx_s"] = [round(px_per_frame * n * args.steps / t / 1e6, 1) for t in per_rank_dt]
+            res["host_ms_per_step"] = round(host_dt / args.steps * 1e3, 4)
+            res["timing"] = "max over ranks of the HIP-event time around the K steps (ranks released together by a barrier)"
+            res["rank_sync_backend"] = backend
+            ref = args.ref_1gpu_mpx or cache_1gpu_load(cache_key(args, wl, W, H))
+            if ref:
+                res["ref_1gpu_Mpx_s"] = round(ref, 1)
+                res["ref_1gpu_source"] = "--ref-1gpu-mpx" if args.ref_1gpu_mpx else "gpurun_out/bench_1gpu_cache.json"
+                res["efficiency_vs_1gpu"] = round(res["value"] / (world * ref), 4)
+        elif not one_dev:
+            cache_1gpu_store(cache_key(args, wl, W, H), res["value"], n)
         if eighth is not None:
             res["eighth_gpu"] = eighth
         if world == 1 and not args.no_cpu_baseline and wl in ("blend_flush", "blend"):

@@ -139,8 +139,23 @@ typedef struct {
     uint8_t dst_argb8565;     /* 1: dst is the 3-byte ARGB8565 layout {c.lo, c.hi, A} that lv_draw_sw_blend_basic draws   */
                               /* into when disp->driver->screen_transp is set (lv_draw_sw_blend.c:129-133, 177-184):    */
                               /* fill_argb / map_argb semantics; dst_frame_stride stays in pixels (3 bytes each)       */
-    uint8_t reserved;
+    uint8_t flags;            /* LVGPU_BLEND_FLAG_* bits, 0 = the behaviour described above                          */
 } lvgpu_blend_batch_t;
+
+/*
+ * lvgpu_blend_batch_t.flags.
+ * LVGPU_BLEND_FLAG_DISCARD_DST  lvgpu_blend_flush_batch only (LVGPU_ERR_ARG anywhere else): the caller does not need the
+ *     blended draw buffer after the flush, only the panel image.  That is the reference's own configuration: its port
+ *     forces full_refresh (src/lv_port.c:241), so LVGL redraws the whole buffer on every refresh
+ *     (libraries/lvgl/src/core/lv_refr.c:633-642) and what the previous refresh left in it is never read.  Where the
+ *     blend and the flush run as one pass over memory the write-back of dst is skipped (8 instead of 10 bytes per pixel
+ *     for an ARGB8888 image) and dst keeps the pixels it had before the call; where they run as two passes dst holds
+ *     the blended pixels as without the flag.  Either way the panel image is the same as without the flag, and the
+ *     contents of dst afterwards are unspecified (one of the two).  Not for displays that keep drawing into the buffer:
+ *     partial refresh (full_refresh 0 with a draw buffer smaller than the screen still redraws each part whole, which
+ *     is fine; direct_mode, where the buffer IS the frame that accumulates, is not) and anything that reads dst back.
+ */
+#define LVGPU_BLEND_FLAG_DISCARD_DST 0x04
 
 int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
 

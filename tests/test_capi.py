@@ -235,6 +235,29 @@ def test_panel_transactions_match_the_restated_panel_driver(oracle):
         lvgpu.axs15231b_transactions(chunks[0], bits_per_pixel=12)
 
 
+def test_panel_transactions_rebuild_the_panel_image(oracle):
+    """The framing consumed: the oracle's panel image of a flushed frame, cut into the transport chunks and framed as
+    the driver frames them, fed to a model of the panel's frame memory (tests/util_panel.py), gives that image back --
+    RAMWR once, RAMWRC for every later chunk, every pixel written exactly once.  (The same walk over a panel image
+    that a fused GPU launch produced is tests/test_gpu_wire.py.)  Parity unpinned, as above."""
+    import numpy as np
+    from util_panel import RAMWR, RAMWRC, PanelModel, send
+    from vvc_amd import lvgpu
+    rng = np.random.default_rng(3)
+    for rot, W, H, trans in [(1, 480, 320, 15360), (0, 320, 480, 15360), (3, 480, 320, 15360), (2, 320, 480, 15360),
+                             (1, 200, 96, 1000), (2, 100, 37, 450)]:
+        frame = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+        img = oracle.flush_frame(frame, W, H, rot, 0)
+        hor, ver = (H, W) if rot in (1, 3) else (W, H)
+        for qspi in (True, False):
+            m = PanelModel(hor, ver, qspi)
+            chunks = send(lvgpu, img.tobytes(), (0, 0, W - 1, H - 1), W, H, rot, trans, m)
+            per = 2 if qspi else 3
+            assert m.log[per - 1] == RAMWR and all(c == RAMWRC for c in m.log[2 * per - 1::per])
+            assert len(chunks) > 1 and (m.written == 1).all()
+            assert m.gram.tobytes() == img.tobytes(), (rot, W, H, qspi)
+
+
 def _plan_of_scene(path, W=480, H=320, flush=1):
     """lvgpu_blend_list_plan on a golden display list; the pointers are placeholders (the plan never touches memory)."""
     from util import load_scene

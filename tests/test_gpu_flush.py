@@ -245,3 +245,61 @@ def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
             got = to_np(out, np.uint16).reshape(N, -1)
             for f in range(N):
                 assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 1 - swap)), (swap, fmt, opa, f)
+
+
+@pytest.mark.parametrize("rot", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape,fmt", [((480, 320), 2), ((480, 320), 1), ((480, 328), 2), ((200, 96), 1), ((135, 240), 2),
+                                       ((466, 30), 4), ((64, 64), 0), ((3840, 24), 2)])
+def test_blend_flush_discard_dst(gpu, oracle, rot, shape, fmt):
+    """LVGPU_BLEND_FLAG_DISCARD_DST (the reference's full_refresh configuration, src/lv_port.c:241: the draw buffer is
+    dead once flushed): the panel image is what the call gives without the flag, and wherever blend and flush run as one
+    pass the draw buffer keeps the pixels it had."""
+    W, H = shape
+    N = 3
+    rng = np.random.default_rng(W + 7 * H + rot + fmt)
+    area = (0, 0, W - 1, H - 1)
+    for swap in (1, 0):
+        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        dst[1].reshape(-1)[: (W * H) // 2] = 0
+        color, opa = int(rng.integers(0, 65536)), (255 if fmt else 137)
+        src = mask = None
+        if fmt == 1:
+            src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+            mask = rand_mask(rng, (N, H, W))
+        elif fmt == 2:
+            src = rng.integers(0, 1 << 32, (N, H, W), dtype=np.uint32)
+        elif fmt == 4:
+            src = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+        exp = dst.copy()
+        for f in range(N):
+            if fmt in (2, 4):
+                oracle.img_blend(exp[f], area, area, area, src[f], fmt, opa, swap, W)
+            else:
+                oracle.blend(exp[f], area, area, area, src=None if src is None else src[f], color=color,
+                             mask=None if mask is None else mask[f], opa=opa, swap=swap)
+        d = to_dev(dst)
+        dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None,
+                           flags=gpu.FLAG_DISCARD_DST)
+        out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
+        one_pass = "fused" in gpu.last_kernel()
+        got = to_np(out, np.uint16).reshape(N, -1)
+        for f in range(N):
+            assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 1 - swap)), (swap, f, gpu.last_kernel())
+        after = to_np(d, np.uint16)
+        assert np.array_equal(after, dst if one_pass else exp), (swap, gpu.last_kernel())
+        assert one_pass or (W * H) % 8, "every whole-buffer blend on the 8-pixel grid is expected to run as one pass"
+
+
+def test_discard_dst_is_for_the_fused_call_only(gpu):
+    d = to_dev(np.zeros((1, 8, 8), np.uint16))
+    dsc = gpu.BlendDsc((0, 0, 7, 7), color=1, flags=gpu.FLAG_DISCARD_DST)
+    with pytest.raises(gpu.LvgpuError) as e:
+        gpu.lv_draw_sw_blend(gpu.DrawCtx(d), dsc)
+    assert e.value.code == -1 and "flags" in str(e.value)
+    # a blend that does not cover the buffer runs as two passes: the flag is accepted and the buffer holds the blend
+    d2 = to_dev(np.zeros((1, 16, 16), np.uint16))
+    out = gpu.blend_flush(gpu.DrawCtx(d2), gpu.BlendDsc((0, 0, 7, 7), color=0x1234, flags=gpu.FLAG_DISCARD_DST), 1)
+    h = to_np(d2, np.uint16)
+    assert (h[0, :8, :8] == 0x1234).all() and (h[0, 8:] == 0).all()
+    assert (to_np(out, np.uint16).reshape(16, 16)[:8, 8:] == 0x1234).all()

@@ -10,6 +10,13 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(world):
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "OMP_NUM_THREADS": "1"})
@@ -20,7 +27,7 @@ def _run(world):
     else:
         out = subprocess.check_output(
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-             "--master-addr", "127.0.0.1", "--master-port", "29653", worker], env=env, timeout=300,
+             "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker], env=env, timeout=300,
             stderr=subprocess.DEVNULL)
     return json.loads(out.decode().strip().splitlines()[-1])
 

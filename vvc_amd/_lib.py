@@ -41,7 +41,7 @@ class BlendBatch(C.Structure):
         ("mask", C.c_void_p), ("mask_frame_stride", C.c_int64), ("mask_area", Area),
         ("n_frames", C.c_int32), ("src_format", C.c_int32),
         ("color", C.c_uint16), ("mask_res", C.c_uint8), ("opa", C.c_uint8),
-        ("blend_mode", C.c_uint8), ("color_16_swap", C.c_uint8), ("dst_argb8565", C.c_uint8), ("reserved", C.c_uint8),
+        ("blend_mode", C.c_uint8), ("color_16_swap", C.c_uint8), ("dst_argb8565", C.c_uint8), ("flags", C.c_uint8),
     ]
 
 
@@ -86,10 +86,11 @@ def lib():
             "There is no CPU fallback." % LIB_PATH)
     # torch brings its own copy of the HIP runtime; when it is to be used in the same process (device memory for the
     # tests and bench.py) it has to be loaded first, or the process ends up with two runtimes of which the second sees
-    # no device.  Without torch installed the library is loaded on its own.
+    # no device.  Without torch -- not installed, or installed but unable to load its own libraries -- the library is
+    # loaded on its own.
     try:
         import torch  # noqa: F401
-    except ImportError:
+    except Exception:
         pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t

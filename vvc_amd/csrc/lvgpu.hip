@@ -107,7 +107,7 @@ enum Resolve { R_NOOP = 0, R_WORK = 1 };
 
 // lv_draw_sw_blend (:95-106) + lv_draw_sw_blend_basic (:108-204) up to the fill_normal/map_normal dispatch.
 // Returns R_NOOP / R_WORK or a negative error; on R_WORK `a` describes the clipped area.
-int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & area)
+int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & area, unsigned allowed_flags = 0)
 {
     memset(&a, 0, sizeof(a));
     if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
@@ -121,6 +121,7 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
     const bool own_alpha = d->src_format >= LVGPU_SRC_ARGB8888;
     if(own_alpha && d->mask) return fail(LVGPU_ERR_UNSUPPORTED, "a mask on top of a source with its own alpha");
     if(d->blend_mode > LVGPU_BLEND_REPLACE) return fail(LVGPU_ERR_ARG, "bad blend_mode %d", d->blend_mode);
+    if(d->flags & ~allowed_flags) return fail(LVGPU_ERR_ARG, "flags 0x%02x: this entry point takes 0x%02x only", d->flags, allowed_flags);
 
     if(d->opa <= 2) return R_NOOP;                                            // :98  LV_OPA_MIN
     if(!intersect(area, d->blend_area, d->clip_area)) return R_NOOP;          // :101
@@ -360,8 +361,14 @@ bool tile_ok(const BlendArgs & a, int fmt)
     // a good part: up to 384 rows (480x272 68 against 63 %) and from 513 to 1536 (1024x600 62 against 54 %, 1080p 64
     // against 61 %); from 385 to 512 rows and on 4K canvases k_tile_col is level or ahead (464x464 66 against 64 %).
     if((a.h % 32) != 0) {
-        if(a.h <= 256) return false;
-        if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 512 && a.h <= 1536))) return false;
+        // LVGPU_QT_KERNEL=any|col in the environment (read at every call) overrides the choice: a switch for measuring
+        if(const char * e = getenv("LVGPU_QT_KERNEL")) {
+            if(e[0] == 'a') return false;
+        }
+        else {
+            if(a.h <= 256) return false;
+            if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 512 && a.h <= 1536))) return false;
+        }
     }
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;
 }
@@ -1072,7 +1079,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     hipStream_t st = (hipStream_t)stream;
     BlendArgs a;
     lvgpu_area_t area;
-    int r = resolve_blend(&d->blend, a, area);
+    int r = resolve_blend(&d->blend, a, area, LVGPU_BLEND_FLAG_DISCARD_DST);
     if(r < 0) return r;
     const lvgpu_blend_batch_t & b = d->blend;
     const int W = aw(b.buf_area), H = ah(b.buf_area);
@@ -1089,6 +1096,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
         // blend must cover the whole buffer row by row (dst_stride == W holds, source and mask keep their own strides)
         const bool any = transposing && !ok;
         if(ok || any) {
+            a.discard_dst = (b.flags & LVGPU_BLEND_FLAG_DISCARD_DST) ? 1 : 0;
             uint32_t * owned = nullptr;
             int rc = prepare_first_nb(a, st, &owned);
             if(rc != LVGPU_OK) return rc;
@@ -1122,6 +1130,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
             return rc;
         }
         a.out = nullptr;
+        a.discard_dst = 0;
     }
     if(r == R_WORK) {
         int rc = launch_blend(a, b.src_format, st);

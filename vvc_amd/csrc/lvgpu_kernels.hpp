@@ -42,6 +42,7 @@ struct BlendArgs {
     int raw_opa;           // dsc->opa as given (ARGB8565 destination path)
     int raw_mode;          // dsc->blend_mode as given
     int has_mask;          // a per-pixel alpha exists (mask buffer or source alpha)
+    int discard_dst;       // fused blend + flush only: the blended pixels go to out alone, dst is left as it is
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2).  Remap the block id
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
             uint4 r = d[u];
             if(BLEND) {
                 r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], g * 8, fnb);
-                if(fast == FAST_OPAQUE) store_write_once(dst + (size_t)g * 8, r);
+                if(a.discard_dst) {}
+                else if(fast == FAST_OPAQUE) store_write_once(dst + (size_t)g * 8, r);
                 else *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.out) {
@@ -379,6 +381,34 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
                 else store_streaming(out + (size_t)g * 8, r);
             }
         }
+    }
+}
+
+// The register transpose of the tile kernels.  A lane owns an 8x8-pixel block and holds NR of its rows (phase p of
+// 8 / NR: rows p*NR .. p*NR + NR - 1) as 16-byte groups r[0..NR).  Column j of the block becomes an 8-pixel piece of
+// a panel row, ordered along that row; NR rows make NR / 2 dwords of it (one v_perm_b32 per dword), which go to the
+// 16-byte LDS chunk col0[j * stride] at the place their rows have in the piece: ascending for 270 degrees, descending
+// for 90.  With NR = 8 a chunk is written whole; with NR = 4 or 2 a lane never holds more than NR rows of source and
+// destination pixels at a time, which is what sets the kernels' register count.
+template <int NR>
+__device__ __forceinline__ void put_transposed(uint4 * col0, int stride, const uint4 * r, int p, bool r90)
+{
+    constexpr int NW = NR / 2;
+    const int off = r90 ? (8 / NR - 1 - p) * NW : p * NW;
+#pragma unroll
+    for(int j = 0; j < 8; j++) {
+        uint32_t o[NW];
+#pragma unroll
+        for(int k = 0; k < NW; k++) {
+            auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
+            const uint32_t lo = r90 ? word(r[NR - 1 - 2 * k]) : word(r[2 * k]);
+            const uint32_t hi = r90 ? word(r[NR - 2 - 2 * k]) : word(r[2 * k + 1]);
+            o[k] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        uint32_t * c = reinterpret_cast<uint32_t *>(col0 + j * stride) + off;
+        if(NW == 4) *reinterpret_cast<uint4 *>(c) = make_uint4(o[0], o[NW > 1 ? 1 : 0], o[NW > 2 ? 2 : 0], o[NW > 3 ? 3 : 0]);
+        else if(NW == 2) *reinterpret_cast<uint2 *>(c) = make_uint2(o[0], o[NW > 1 ? 1 : 0]);
+        else *c = o[0];
     }
 }
 
@@ -397,7 +427,8 @@ constexpr int TILE = 64;
 // CU, and small workgroups let it do so in steps of two waves (measured: +1 % fused, +1 % rotation alone).
 constexpr int TILE_WPB = 2;
 
-template <int SRC>
+// NR: rows of its 8x8 block a lane loads, blends and transposes at a time (8, 4 or 2; see put_transposed).
+template <int SRC, int NR>
 __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpf,
                                               uint32_t n_tiles)
 {
@@ -427,53 +458,41 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
     const int x0 = tx * TILE + bx * 8, y0 = ty * TILE + by * 8;
     const bool inside = live && x0 < W && y0 < H;
 
-    uint4 r[8];
     if(inside) {
         uint16_t * dst = a.dst + (long long)f * a.dst_fs;
         const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
         const long long src_px0 = (long long)f * a.src_fs;
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
         const int fast = fast_path<SRC>(a);
-        uint4 d[8];
-        uint2 mk[8];
-        uint32_t sw[8][SrcWords<SRC>::N];
-#pragma unroll
-        for(int i = 0; i < 8; i++) {
-            const size_t p = (size_t)(y0 + i) * W + x0;
-            d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
-            mk[i] = make_uint2(0, 0);
-            if(BLEND) {
-                if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
-                if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
-            }
-        }
-#pragma unroll
-        for(int i = 0; i < 8; i++) {
-            r[i] = d[i];
-            if(BLEND) {
-                const size_t p = (size_t)(y0 + i) * W + x0;
-                r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
-                *reinterpret_cast<uint4 *>(dst + p) = r[i];
-            }
-            if(a.swap_out) r[i] = swap_group(r[i]);
-        }
-        // register transpose: column j of the block becomes an 8-pixel segment ordered along the output row
         const bool r90 = a.rot == 1;
+        uint4 * col0 = &lds[wave][bx * 64 + (by ^ bx)];  // column j of the block: chunk (bx*8 + j) * 8 + (by ^ bx)
 #pragma unroll
-        for(int j = 0; j < 8; j++) {
-            uint32_t o[4];
+        for(int ph = 0; ph < 8 / NR; ph++) {
+            uint4 d[NR], r[NR];
+            uint2 mk[NR];
+            uint32_t sw[NR][SrcWords<SRC>::N];
 #pragma unroll
-            for(int m = 0; m < 4; m++) {
-                // output pixels 2m (low half) and 2m+1 (high half) of the segment
-                const uint4 & ra90 = r[7 - 2 * m], & rb90 = r[6 - 2 * m];
-                const uint4 & ra27 = r[2 * m], & rb27 = r[2 * m + 1];
-                auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
-                const uint32_t lo = r90 ? word(ra90) : word(ra27);
-                const uint32_t hi = r90 ? word(rb90) : word(rb27);
-                o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            for(int i = 0; i < NR; i++) {
+                const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
+                d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
+                mk[i] = make_uint2(0, 0);
+                if(BLEND) {
+                    if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
+                    if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
+                }
             }
-            const int xl = bx * 8 + j;
-            lds[wave][xl * 8 + (by ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for(int i = 0; i < NR; i++) {
+                r[i] = d[i];
+                if(BLEND) {
+                    const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
+                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + p) = r[i];
+                }
+                if(a.swap_out) r[i] = swap_group(r[i]);
+            }
+            put_transposed<NR>(col0, 8, r, ph, r90);
+            if(NR < 8) __builtin_amdgcn_sched_barrier(0);  // the next rows are not asked for before these are done with
         }
     }
     __syncthreads();  // a block barrier rather than a wave fence: keeping the block's waves in step measured 2 % faster
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
 // instruction (64 lanes x 16 bytes): only the first and the last line of a run are partial.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int COL_WPB = 8;  // 5 to 7 (fewer empty tile slots on 4K, 1080p) and 16 measured slower: the run length counts
-template <int SRC>
+template <int SRC, int NR>
 __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, uint32_t n_blocks)
 {
     __shared__ uint4 lds[64 * 8 * COL_WPB];   // [panel row of the block 0..63][chunk of the run 0..8*COL_WPB-1], swizzled
@@ -530,43 +549,36 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
         const long long src_px0 = (long long)f * a.src_fs;
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
         const int fast = fast_path<SRC>(a);
-        uint4 d[8], r[8];
-        uint2 mk[8];
-        uint32_t sw[8][SrcWords<SRC>::N];
-#pragma unroll
-        for(int i = 0; i < 8; i++) {
-            const size_t p = (size_t)(y0 + i) * W + x0;
-            d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
-            mk[i] = make_uint2(0, 0);
-            if(BLEND) {
-                if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
-                if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
-            }
-        }
-#pragma unroll
-        for(int i = 0; i < 8; i++) {
-            r[i] = d[i];
-            if(BLEND) {
-                const size_t p = (size_t)(y0 + i) * W + x0;
-                r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
-                *reinterpret_cast<uint4 *>(dst + p) = r[i];
-            }
-            if(a.swap_out) r[i] = swap_group(r[i]);
-        }
         // position of this lane's 8 rows in the run, in ascending panel address order
         const int c = r90 ? RUN - 1 - (wave * 8 + by) : wave * 8 + by;
+        uint4 * col0 = &lds[bx * 8 * RUN + (c ^ bx)];          // column j of the block: chunk (bx*8 + j) * RUN + (c ^ bx)
 #pragma unroll
-        for(int j = 0; j < 8; j++) {
-            uint32_t o[4];
+        for(int ph = 0; ph < 8 / NR; ph++) {
+            uint4 d[NR], r[NR];
+            uint2 mk[NR];
+            uint32_t sw[NR][SrcWords<SRC>::N];
 #pragma unroll
-            for(int m = 0; m < 4; m++) {
-                auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
-                const uint32_t lo = r90 ? word(r[7 - 2 * m]) : word(r[2 * m]);
-                const uint32_t hi = r90 ? word(r[6 - 2 * m]) : word(r[2 * m + 1]);
-                o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            for(int i = 0; i < NR; i++) {
+                const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
+                d[i] = fast == FAST_OPAQUE ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4 *>(dst + p);
+                mk[i] = make_uint2(0, 0);
+                if(BLEND) {
+                    if(SRC != SRC_FILL) load_src<SRC>(a.src, src_px0 + (long long)p, sw[i]);
+                    if(mask) mk[i] = *reinterpret_cast<const uint2 *>(mask + p);
+                }
             }
-            const int xl = bx * 8 + j;
-            lds[xl * RUN + (c ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for(int i = 0; i < NR; i++) {
+                r[i] = d[i];
+                if(BLEND) {
+                    const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
+                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + p) = r[i];
+                }
+                if(a.swap_out) r[i] = swap_group(r[i]);
+            }
+            put_transposed<NR>(col0, RUN, r, ph, r90);
+            if(NR < 8) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void k_band(BlendArgs a, int W, in
             uint4 r = d[u];
             if(BLEND) {
                 r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], (uint32_t)band0 + g * 8, fnb);
-                *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
+                if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.swap_out) r = swap_group(r);
             lds[row * (BAND_MAX_W / 8) + (cg ^ (row >> 3))] = r;
@@ -891,9 +903,9 @@ __device__ __forceinline__ void store_group_masked_any(uint16_t * p, uint4 r, ui
 // frame height with as few idle wavefronts as possible; up to 512 rows one workgroup takes a column of tiles whole
 // and writes complete panel rows, which follow each other in memory.  The exchange area is 8 KB of dynamic LDS per
 // wavefront: [panel row of the region 0..63][chunk of the run 0..8*wpb-1], swizzled.
-constexpr int ANY_WPB_MAX = 8, ANY_WPB_MAX_BLEND = 4;  // with the blend fused in, larger workgroups only lose
-template <int SRC>
-__global__ __launch_bounds__(64 * (SRC == SRC_COPY ? ANY_WPB_MAX : ANY_WPB_MAX_BLEND)) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
+constexpr int ANY_WPB_MAX = 8;
+template <int SRC, int NR>
+__global__ __launch_bounds__(64 * ANY_WPB_MAX) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
 {
     extern __shared__ uint4 lds[];
     const int RUN = 8 * wpb;               // 16-byte chunks per output run
@@ -920,78 +932,75 @@ __global__ __launch_bounds__(64 * (SRC == SRC_COPY ? ANY_WPB_MAX : ANY_WPB_MAX_B
         const int nx = W - x0 < 8 ? W - x0 : 8;              // columns of this lane's block that exist
         const bool full_x = nx == 8;
         const uint32_t pmx = (1u << nx) - 1u;
-        uint4 d[8], r[8];
-        uint2 mk[8];
-        uint32_t sw[8][SrcWords<SRC>::N];
+        const int c = r90 ? RUN - 1 - (wave * 8 + by) : wave * 8 + by;
+        uint4 * col0 = &lds[bx * 8 * RUN + (c ^ bx)];
 #pragma unroll
-        for(int i = 0; i < 8; i++) {
-            d[i] = make_uint4(0, 0, 0, 0);
-            mk[i] = make_uint2(0, 0);
-            if(y0 + i >= H) continue;
-            const size_t p = (size_t)(y0 + i) * a.dst_stride + x0;
-            // A block that sticks out of the frame on the right is still loaded with wide accesses wherever another row
-            // follows in the same frame: what they read beyond the row's end is the start of that row (x0 + 8 <= W + 7
-            // < 2 W, and rows lie at least W pixels apart in all three buffers); only the frame's last row, and frames
-            // narrower than a group, are gathered pixel by pixel.  The surplus pixels are never stored.
-            const bool wide = full_x || (W >= 8 && y0 + i + 1 < H);
-            if(fast != FAST_OPAQUE) {
-                if(wide) d[i] = load16_any(dst + p);
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
+        for(int ph = 0; ph < 8 / NR; ph++) {
+            uint4 d[NR], r[NR];
+            uint2 mk[NR];
+            uint32_t sw[NR][SrcWords<SRC>::N];
 #pragma unroll
-                    for(int j = 0; j < 8; j++)
-                        if(j < nx) w[j >> 1] |= (uint32_t)dst[p + j] << ((j & 1) * 16);
-                    d[i] = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-            if(BLEND) {
-                if(SRC != SRC_FILL) {
-                    const long long sp = src_px0 + (long long)(y0 + i) * a.src_stride + x0;
-                    if(wide) load_src_unaligned<SRC>(a.src, sp, sw[i]);
-                    else load_src_guarded<SRC>(a.src, sp, 0, nx, sw[i]);
-                }
-                if(mask) {
-                    const uint8_t * mp = mask + (size_t)(y0 + i) * a.mask_stride + x0;
-                    if(wide) {
-                        const u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(mp);
-                        mk[i] = make_uint2(v.x, v.y);
-                    }
+            for(int i = 0; i < NR; i++) {
+                const int y = y0 + ph * NR + i;
+                d[i] = make_uint4(0, 0, 0, 0);
+                mk[i] = make_uint2(0, 0);
+                if(y >= H) continue;
+                const size_t p = (size_t)y * a.dst_stride + x0;
+                // A block that sticks out of the frame on the right is still loaded with wide accesses wherever another row
+                // follows in the same frame: what they read beyond the row's end is the start of that row (x0 + 8 <= W + 7
+                // < 2 W, and rows lie at least W pixels apart in all three buffers); only the frame's last row, and frames
+                // narrower than a group, are gathered pixel by pixel.  The surplus pixels are never stored.
+                const bool wide = full_x || (W >= 8 && y + 1 < H);
+                if(fast != FAST_OPAQUE) {
+                    if(wide) d[i] = load16_any(dst + p);
                     else {
+                        uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
                         for(int j = 0; j < 8; j++)
-                            if(j < nx) {
-                                const uint32_t m = mp[j];
-                                if(j < 4) mk[i].x |= m << (j * 8);
-                                else mk[i].y |= m << ((j - 4) * 8);
-                            }
+                            if(j < nx) w[j >> 1] |= (uint32_t)dst[p + j] << ((j & 1) * 16);
+                        d[i] = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+                if(BLEND) {
+                    if(SRC != SRC_FILL) {
+                        const long long sp = src_px0 + (long long)y * a.src_stride + x0;
+                        if(wide) load_src_unaligned<SRC>(a.src, sp, sw[i]);
+                        else load_src_guarded<SRC>(a.src, sp, 0, nx, sw[i]);
+                    }
+                    if(mask) {
+                        const uint8_t * mp = mask + (size_t)y * a.mask_stride + x0;
+                        if(wide) {
+                            const u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(mp);
+                            mk[i] = make_uint2(v.x, v.y);
+                        }
+                        else {
+#pragma unroll
+                            for(int j = 0; j < 8; j++)
+                                if(j < nx) {
+                                    const uint32_t m = mp[j];
+                                    if(j < 4) mk[i].x |= m << (j * 8);
+                                    else mk[i].y |= m << ((j - 4) * 8);
+                                }
+                        }
                     }
                 }
             }
-        }
 #pragma unroll
-        for(int i = 0; i < 8; i++) {
-            r[i] = d[i];
-            if(BLEND && y0 + i < H) {
-                const size_t p = (size_t)(y0 + i) * a.dst_stride + x0;
-                r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)((y0 + i) * W + x0), fnb);
-                if(full_x) store16_any(dst + p, r[i], false);
-                else store_group_masked_any(dst + p, r[i], pmx);
+            for(int i = 0; i < NR; i++) {
+                const int y = y0 + ph * NR + i;
+                r[i] = d[i];
+                if(BLEND && y < H) {
+                    const size_t p = (size_t)y * a.dst_stride + x0;
+                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)(y * W + x0), fnb);
+                    if(!a.discard_dst) {
+                        if(full_x) store16_any(dst + p, r[i], false);
+                        else store_group_masked_any(dst + p, r[i], pmx);
+                    }
+                }
+                if(a.swap_out) r[i] = swap_group(r[i]);
             }
-            if(a.swap_out) r[i] = swap_group(r[i]);
-        }
-        const int c = r90 ? RUN - 1 - (wave * 8 + by) : wave * 8 + by;
-#pragma unroll
-        for(int j = 0; j < 8; j++) {
-            uint32_t o[4];
-#pragma unroll
-            for(int m = 0; m < 4; m++) {
-                auto word = [j](const uint4 & v) { return j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w)); };
-                const uint32_t lo = r90 ? word(r[7 - 2 * m]) : word(r[2 * m]);
-                const uint32_t hi = r90 ? word(r[6 - 2 * m]) : word(r[2 * m + 1]);
-                o[m] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-            }
-            const int xl = bx * 8 + j;
-            lds[xl * RUN + (c ^ bx)] = make_uint4(o[0], o[1], o[2], o[3]);
+            put_transposed<NR>(col0, RUN, r, ph, r90);
+            if(NR < 8) __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();

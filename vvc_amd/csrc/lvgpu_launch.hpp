@@ -1,7 +1,7 @@
 // lvgpu_launch.hpp -- what the translation units of liblvgpu.so share on the host side.  The kernels are spread
-// over three of them so that they compile side by side: lvgpu.hip (C ABI, argument resolution, the linear, ARGB8565,
-// display-list and conversion kernels), lvgpu_tiles.hip (k_tile, k_tile_col, k_tile_any, k_band) and lvgpu_rows.hip
-// (k_blend_rows).
+// over several of them so that they compile side by side: lvgpu.hip (C ABI, argument resolution, the linear, ARGB8565,
+// display-list and conversion kernels), lvgpu_tiles.hip (k_tile, k_band), lvgpu_tiles_col.hip (k_tile_col),
+// lvgpu_tiles_any.hip (k_tile_any) and lvgpu_rows.hip (k_blend_rows).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,6 +18,7 @@ int host_fail(int code, const char * text);
 constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
                    BAND_PAD_LDS = 40 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes);
+int tile_rows_per_phase(const char * env_name, int chosen);
 
 // One launch each; fmt is a SrcFmt (SRC_COPY: rotation alone).  Shapes are checked by the callers (tile_ok, ...).
 int launch_tile(int fmt, const BlendArgs & a, hipStream_t st);

@@ -20,6 +20,7 @@ LV_BLEND_MODE_NORMAL, LV_BLEND_MODE_ADDITIVE, LV_BLEND_MODE_SUBTRACTIVE, LV_BLEN
 LV_DISP_ROT_NONE, LV_DISP_ROT_90, LV_DISP_ROT_180, LV_DISP_ROT_270 = 0, 1, 2, 3
 SRC_FILL, SRC_RGB565, SRC_ARGB8888, SRC_RGBA8888, SRC_ARGB8565 = 0, 1, 2, 3, 4
 SYNTH_U16, SYNTH_MASK_UI, SYNTH_MASK_UNI, SYNTH_ARGB_UI, SYNTH_ARGB_UNI = 0, 1, 2, 3, 4
+FLAG_NO_AA, FLAG_OWNS_ROWS, FLAG_DISCARD_DST = 0x01, 0x02, 0x04   # LVGPU_BLEND_FLAG_*
 
 _SRC_ELEM_BYTES = {SRC_RGB565: 2, SRC_ARGB8888: 4, SRC_RGBA8888: 4, SRC_ARGB8565: 3}
 
@@ -88,7 +89,7 @@ class BlendDsc:
     for SRC_ARGB8565; mask_buf: [h, w] or [n_frames, h, w] uint8."""
 
     def __init__(self, blend_area, src_buf=None, color=0, mask_buf=None, mask_res=LV_DRAW_MASK_RES_CHANGED,
-                 mask_area=None, opa=LV_OPA_COVER, blend_mode=LV_BLEND_MODE_NORMAL, src_format=None):
+                 mask_area=None, opa=LV_OPA_COVER, blend_mode=LV_BLEND_MODE_NORMAL, src_format=None, flags=0):
         self.blend_area = Area.of(blend_area)
         self.src_buf = src_buf
         self.color = int(color)
@@ -100,6 +101,7 @@ class BlendDsc:
         if src_format is None:
             src_format = SRC_FILL if src_buf is None else SRC_RGB565
         self.src_format = src_format
+        self.flags = int(flags)
 
 
 def _fill_batch(ctx, dsc):
@@ -138,6 +140,7 @@ def _fill_batch(ctx, dsc):
     b.opa = dsc.opa
     b.blend_mode = dsc.blend_mode
     b.color_16_swap = ctx.color_16_swap
+    b.flags = dsc.flags
     return b
 
 
