@@ -92,6 +92,10 @@ int lvgpu_memcpy_h2d(void * dev_dst, const void * host_src, size_t bytes, void *
 int lvgpu_memcpy_d2h(void * host_dst, const void * dev_src, size_t bytes, void * stream);
 int lvgpu_memset(void * dev_dst, int value, size_t bytes, void * stream);
 int lvgpu_stream_synchronize(void * stream);
+/* A stream of the calling thread's current device that does not synchronise with the default stream
+ * (hipStreamCreateWithFlags, hipStreamNonBlocking): one per host thread is what a multi-device host uses, see
+ * examples/multi_gpu_blend_flush.c.  Released with lvgpu_stream_destroy. */
+int lvgpu_stream_create(void ** stream);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* Blend: lv_draw_sw_blend over a batch of frames                                                               */
@@ -156,6 +160,18 @@ typedef struct {
  *     is fine; direct_mode, where the buffer IS the frame that accumulates, is not) and anything that reads dst back.
  */
 #define LVGPU_BLEND_FLAG_DISCARD_DST 0x04
+/*
+ * LVGPU_BLEND_FLAG_OWNS_ROWS  the caller owns the buffer rows the clipped area touches, in every frame, for the duration
+ *     of the call: nothing else writes any pixel of those rows meanwhile (a single LVGL display does: it draws one thing
+ *     at a time, libraries/lvgl/src/misc/lv_timer.c:72-77; two streams drawing side-by-side widgets into the same rows do
+ *     not).  The blend of an area narrower than its buffer (the shape LVGL issues per object part,
+ *     libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:125-129) may then write every row in whole aligned 64-byte pieces:
+ *     pixels of those rows beside the area that share a piece with it are read and written back with the value they
+ *     hold, never beyond the ends of the buffer row.  Results are the same with and without the flag; partly written
+ *     pieces cost the memory system a read-modify-write, whole ones do not (201x101 area: 47 -> 6x % of the HBM peak).
+ *     Display lists set it for the items they run on their own, since a list owns its buffers by definition.
+ */
+#define LVGPU_BLEND_FLAG_OWNS_ROWS 0x02
 
 int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
 

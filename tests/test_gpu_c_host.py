@@ -43,3 +43,34 @@ def test_c_host_program(gpu, oracle, rot):
     assert int(vals["list_panel_images"]) == oracle.checksum(pan, 0)
     assert vals["list_kernel"] == "k_blend_list(fused)" and int(vals["list_launches"]) == 1
     assert int(vals["list_steps"]) < 42 * 40  # far fewer steps than items x tiles: the rows are batched
+
+
+MULTI = os.path.join(ROOT, "examples", "multi_gpu_blend_flush")
+
+
+@pytest.mark.parametrize("rot", [1, 0])
+def test_multi_device_c_host_sharding(gpu, oracle, rot):
+    """examples/multi_gpu_blend_flush.c: one host thread + stream per shard, lvgpu_init per thread, contiguous frame
+    ranges, per-shard checksums added on the host.  Rehearsed with two and three threads on device 0: the totals equal
+    the one-shard run's and the oracle's, whatever the partition (25 frames do not divide by 2 or 3)."""
+    if not os.path.exists(MULTI):
+        pytest.fail("examples/multi_gpu_blend_flush is not built (make -C examples; __graft_entry__.build() does it)")
+    n, W, H = 25, 480, 320
+    px = W * H
+    dst = oracle.synth(oracle.SYNTH_U16, 0x5EED0001, 0, n * px)
+    src = oracle.synth(oracle.SYNTH_ARGB_UI, 0x5EED0002, 0, n * px)
+    panel = np.empty(n * px, np.uint16)
+    oracle.argb_blend_flush_batch(dst, src, panel, W, H, n, rot, 1, 4)
+    want = (oracle.checksum(dst, 0), oracle.checksum(panel, 0))
+    for shards in (1, 2, 3):
+        out = subprocess.check_output([MULTI, str(n), str(shards), "1", str(rot)], timeout=120).decode()
+        lines = out.strip().splitlines()
+        vals = dict(line.split(" ", 1) for line in lines if not line.startswith("shard "))
+        per = [line for line in lines if line.startswith("shard ")]
+        assert len(per) == shards and all("fused" in line for line in per), out
+        ranges = [tuple(int(v) for v in line.split()[5].split("..")) for line in per]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert (int(vals["draw_buffers"]), int(vals["panel_images"])) == want, (shards, out)
+    # more devices than the machine has is an argument error, not a crash
+    p = subprocess.run([MULTI, "8", "2", "99"], capture_output=True, timeout=60)
+    assert p.returncode == 1 and b"bad arguments" in p.stderr

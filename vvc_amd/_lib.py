@@ -132,6 +132,7 @@ def lib():
         "lvgpu_synth": (C.c_int, [vp, C.c_int, u64, u64, sz, vp]),
         "lvgpu_checksum": (C.c_int, [vp, C.c_int, u64, sz, vp, vp]),
         "lvgpu_stream_create_cu_mask": (C.c_int, [C.POINTER(vp), vp, C.c_int]),
+        "lvgpu_stream_create": (C.c_int, [C.POINTER(vp)]),
         "lvgpu_stream_destroy": (C.c_int, [vp]),
         "lvgpu_xcc_census": (C.c_int, [vp, C.c_int, vp]),
         "lvgpu_lvgl_bind": (None, [vp, vp, vp]),

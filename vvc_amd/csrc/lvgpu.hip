@@ -105,6 +105,17 @@ int scratch_on_current_device(uint32_t ** out)
 
 enum Resolve { R_NOOP = 0, R_WORK = 1 };
 
+// Pixels per whole piece under LVGPU_BLEND_FLAG_OWNS_ROWS: 32 (64 bytes, the unit in which the L2 writes to memory).
+// LVGPU_ROWS_SPAN=8|16|32|64 in the environment (read at every call) changes it: a switch for measuring.
+int rows_span_px()
+{
+    if(const char * e = getenv("LVGPU_ROWS_SPAN")) {
+        const int v = atoi(e);
+        if(v == 8 || v == 16 || v == 32 || v == 64) return v;
+    }
+    return 32;
+}
+
 // lv_draw_sw_blend (:95-106) + lv_draw_sw_blend_basic (:108-204) up to the fill_normal/map_normal dispatch.
 // Returns R_NOOP / R_WORK or a negative error; on R_WORK `a` describes the clipped area.
 int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & area, unsigned allowed_flags = 0)
@@ -163,6 +174,10 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
         a.mask_stride = aw(d->mask_area);                                     // :158
         a.mask_fs = d->mask_frame_stride;
         a.mask = mask + (size_t)a.mask_stride * (area.y1 - d->mask_area.y1) + (area.x1 - d->mask_area.x1);   // :159
+    }
+    if(d->flags & LVGPU_BLEND_FLAG_OWNS_ROWS) {
+        a.span_px = rows_span_px();
+        a.row_x0 = area.x1 - d->buf_area.x1;
     }
     a.color = a.swap ? bswap16(d->color) : d->color;
     a.raw_opa = d->opa;
@@ -864,6 +879,7 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     if(geom->dst == nullptr) return fail(LVGPU_ERR_ARG, "dst is NULL");
 
     // resolve everything first: nothing is launched when any item is malformed
+    const bool argb_list = geom->dst_argb8565 != 0;
     std::vector<BlendArgs> ra((size_t)n_items);
     std::vector<lvgpu_area_t> areas((size_t)n_items);
     std::vector<int> res((size_t)n_items);
@@ -873,7 +889,11 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
            memcmp(&d.buf_area, &geom->buf_area, sizeof(lvgpu_area_t)) != 0 || (d.color_16_swap != 0) != (geom->color_16_swap != 0) ||
            (d.dst_argb8565 != 0) != (geom->dst_argb8565 != 0))
             return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
-        res[i] = resolve_blend(&d, ra[i], areas[i]);
+        res[i] = resolve_blend(&d, ra[i], areas[i], LVGPU_BLEND_FLAG_OWNS_ROWS);
+        if(res[i] >= 0 && !argb_list) {  // a list owns its buffers: items run on their own may write whole pieces of their rows
+            ra[i].span_px = rows_span_px();
+            ra[i].row_x0 = areas[i].x1 - geom->buf_area.x1;
+        }
         if(res[i] < 0) {
             g_err = "item " + std::to_string(i) + ": " + g_err;
             return res[i];
@@ -1035,7 +1055,7 @@ int lvgpu_blend_batch(const lvgpu_blend_batch_t * d, void * stream)
     BlendArgs a;
     lvgpu_area_t area;
     g_last_kernel = "";
-    int r = resolve_blend(d, a, area);
+    int r = resolve_blend(d, a, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
     if(r <= 0) return r;
     return launch_blend(a, d->src_format, (hipStream_t)stream, d->dst_argb8565 != 0);
 }
@@ -1048,7 +1068,7 @@ int lvgpu_blend_batch_noalloc(const lvgpu_blend_batch_t * d, void * stream)
     if(d != nullptr && d->n_frames > LVGPU_NOALLOC_MAX_FRAMES)
         return fail(LVGPU_ERR_ARG, "lvgpu_blend_batch_noalloc takes at most %d frames per call (%d given); split the batch or use "
                     "lvgpu_blend_batch", LVGPU_NOALLOC_MAX_FRAMES, d->n_frames);
-    int r = resolve_blend(d, a, area);
+    int r = resolve_blend(d, a, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
     if(r <= 0) return r;
     uint32_t * buf = nullptr;
     r = scratch_on_current_device(&buf);
@@ -1079,7 +1099,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     hipStream_t st = (hipStream_t)stream;
     BlendArgs a;
     lvgpu_area_t area;
-    int r = resolve_blend(&d->blend, a, area, LVGPU_BLEND_FLAG_DISCARD_DST);
+    int r = resolve_blend(&d->blend, a, area, LVGPU_BLEND_FLAG_DISCARD_DST | LVGPU_BLEND_FLAG_OWNS_ROWS);
     if(r < 0) return r;
     const lvgpu_blend_batch_t & b = d->blend;
     const int W = aw(b.buf_area), H = ah(b.buf_area);
@@ -1189,7 +1209,7 @@ int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_
             return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
         BlendArgs ra;
         lvgpu_area_t area;
-        int r = resolve_blend(&d, ra, area);
+        int r = resolve_blend(&d, ra, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
         if(r < 0) {
             g_err = "item " + std::to_string(i) + ": " + g_err;
             return r;
@@ -1512,6 +1532,14 @@ int lvgpu_stream_create_cu_mask(void ** stream, const uint32_t * mask_words, int
     if(!stream || !mask_words || n_words <= 0) return fail(LVGPU_ERR_ARG, "bad arguments");
     hipStream_t st;
     HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+    *stream = st;
+    return LVGPU_OK;
+}
+int lvgpu_stream_create(void ** stream)
+{
+    if(!stream) return fail(LVGPU_ERR_ARG, "NULL out pointer");
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     *stream = st;
     return LVGPU_OK;
 }
