@@ -18,8 +18,7 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
     flush_180_466          the flush alone, half turn, on the same frames (pixel count not a multiple of 8)
     clipped_small, clipped_large   lv_draw_sw_blend of a per-frame RGB565 image + A8 mask over a clipped,
                            misaligned area (201x101 at an odd x / 468x296 at x = 3) of 480x320 buffers; pixels
-                           counted are the area's (7 B/px); clipped_*_owned: the same with LVGPU_BLEND_FLAG_OWNS_ROWS (the
-                           caller owns the rows the area touches: every row is written in whole 64-byte pieces)
+                           counted are the area's (7 B/px)
     fill_translucent       fill_normal without mask, translucent (premultiplied formula + scan-order pre-pass), 4 B/px
     fill_opaque / map_opaque   lv_color_fill per row (2 B/px, write only) / row copy (4 B/px)
     fill_masked            fill_normal with an A8 mask at opa 255 (5 B/px)
@@ -67,12 +66,10 @@ WORKLOADS = {
     "blend_rgb565a8": (7, 480, 320, 4096), "blend_flush_rgb565a8": (9, 480, 320, 4096), "scene": (4, 480, 320, 4096),
     "blend_flush_4k": (10, 3840, 2160, 64), "blend_flush_466": (10, 466, 466, 2048), "flush_180_466": (4, 466, 466, 2048),
     "clipped_small": (7, 480, 320, 4096), "clipped_large": (7, 480, 320, 4096),
-    "clipped_small_owned": (7, 480, 320, 4096), "clipped_large_owned": (7, 480, 320, 4096),
     "fill_translucent": (4, 480, 320, 4096), "fill_opaque": (2, 480, 320, 4096), "map_opaque": (4, 480, 320, 4096),
     "fill_masked": (5, 480, 320, 4096), "fill_masked_argb": (7, 480, 320, 4096),
 }
-CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300),
-                 "clipped_small_owned": (11, 10, 211, 110), "clipped_large_owned": (3, 5, 470, 300)}
+CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300)}
 KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_tiles.hip", "lvgpu_tiles_col.hip", "lvgpu_tiles_any.hip", "lvgpu_rows.hip", "lvgpu_launch.hpp", "lvgpu_kernels.hpp", "lvgpu_list.hpp",
                   "lvgpu_px.hpp")
 
@@ -427,8 +424,7 @@ def main(argv=None):
         px_per_frame = bw * bh
         src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, lo * px_per_frame, (n, bh, bw))
         a8 = lvgpu.synth(mask_kind, SEED_MASK, lo * px_per_frame, (n, bh, bw))
-        dsc = lvgpu.BlendDsc(ba, src_buf=src16, mask_buf=a8, opa=255,
-                             flags=lvgpu.FLAG_OWNS_ROWS if wl.endswith("_owned") else 0)
+        dsc = lvgpu.BlendDsc(ba, src_buf=src16, mask_buf=a8, opa=255)
     elif wl == "fill_translucent":
         # a colour / opacity pair for which lv_color_mix and lv_color_mix_premult disagree on black (about one pair in
         # twenty does), so that the scan-order pre-pass (first non-black pixel of every frame) runs
@@ -539,9 +535,8 @@ def main(argv=None):
         elif wl in CLIPPED_AREAS:
             ba = CLIPPED_AREAS[wl]
             desc = ("%s: lv_draw_sw_blend of a per-frame RGB565 image + A8 mask (%s) over the clipped area %s of %dx%d "
-                    "buffers, opa 255, LV_COLOR_16_SWAP %d, %d frames per GPU; pixels counted = the area's%s"
-                    % (wl, args.mask, list(ba), W, H, args.swap, n,
-                       "; LVGPU_BLEND_FLAG_OWNS_ROWS (rows written in whole 64-byte pieces)" if wl.endswith("_owned") else ""))
+                    "buffers, opa 255, LV_COLOR_16_SWAP %d, %d frames per GPU; pixels counted = the area's"
+                    % (wl, args.mask, list(ba), W, H, args.swap, n))
         elif wl.startswith("fill") or wl == "map_opaque":
             desc = ("%s: %s over whole %dx%d buffers, LV_COLOR_16_SWAP %d, %d frames per GPU"
                     % (wl, {"fill_translucent": "fill_normal, no mask, opa %d (premultiplied formula + scan-order pre-pass)" % (137 if args.swap else 103),

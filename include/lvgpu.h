@@ -148,6 +148,17 @@ typedef struct {
 
 /*
  * lvgpu_blend_batch_t.flags.
+ * LVGPU_BLEND_FLAG_NO_AA  the display has anti-aliasing switched off (lv_disp_drv_t.antialiasing == 0): every mask value
+ *     -- the bytes of `mask`, or the alpha of a source with its own alpha, whose alpha plane is the mask of the blend
+ *     (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:133-136) -- is rounded to 0 or 255 before it is used,
+ *     `m > 128 ? LV_OPA_COVER : LV_OPA_TRANSP` (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:150-156).  The reference
+ *     rounds the caller's mask buffer in place; here the values are rounded as they are loaded and the buffer is left as
+ *     it is (rounding is idempotent, so a caller that uses the buffer as a mask again sees the same pixels either way; a
+ *     caller that reads the bytes back as something else -- LVGL's shadow renderer takes opacities from a buffer it has
+ *     blended out of, libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:572,661 -- has to round them itself, which is what
+ *     lvgpu_blend of lvgpu_lvgl.h does instead of setting this flag).  Accepted by
+ *     every entry point that takes a lvgpu_blend_batch_t; without a mask (or with mask_res FULL_COVER) it does nothing,
+ *     as in the reference.
  * LVGPU_BLEND_FLAG_DISCARD_DST  lvgpu_blend_flush_batch only (LVGPU_ERR_ARG anywhere else): the caller does not need the
  *     blended draw buffer after the flush, only the panel image.  That is the reference's own configuration: its port
  *     forces full_refresh (src/lv_port.c:241), so LVGL redraws the whole buffer on every refresh
@@ -159,19 +170,8 @@ typedef struct {
  *     partial refresh (full_refresh 0 with a draw buffer smaller than the screen still redraws each part whole, which
  *     is fine; direct_mode, where the buffer IS the frame that accumulates, is not) and anything that reads dst back.
  */
+#define LVGPU_BLEND_FLAG_NO_AA 0x01
 #define LVGPU_BLEND_FLAG_DISCARD_DST 0x04
-/*
- * LVGPU_BLEND_FLAG_OWNS_ROWS  the caller owns the buffer rows the clipped area touches, in every frame, for the duration
- *     of the call: nothing else writes any pixel of those rows meanwhile (a single LVGL display does: it draws one thing
- *     at a time, libraries/lvgl/src/misc/lv_timer.c:72-77; two streams drawing side-by-side widgets into the same rows do
- *     not).  The blend of an area narrower than its buffer (the shape LVGL issues per object part,
- *     libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:125-129) may then write every row in whole aligned 64-byte pieces:
- *     pixels of those rows beside the area that share a piece with it are read and written back with the value they
- *     hold, never beyond the ends of the buffer row.  Results are the same with and without the flag; partly written
- *     pieces cost the memory system a read-modify-write, whole ones do not (201x101 area: 47 -> 6x % of the HBM peak).
- *     Display lists set it for the items they run on their own, since a list owns its buffers by definition.
- */
-#define LVGPU_BLEND_FLAG_OWNS_ROWS 0x02
 
 int lvgpu_blend_batch(const lvgpu_blend_batch_t * dsc, void * stream);
 
@@ -424,6 +424,19 @@ int lvgpu_stream_destroy(void * stream);
 /* Launches n_blocks workgroups on `stream` and adds, per XCD id (0..7), the number of workgroups that ran there to
  * dev_counts8[0..7] (device memory, zero it first): tells which XCDs a CU mask actually selects. */
 int lvgpu_xcc_census(uint32_t * dev_counts8, int n_blocks, void * stream);
+
+/* Counters since the library was loaded, for tests that pin properties no result shows: the device and pinned-memory
+ * allocations the library's entry points have made (hipMalloc, hipMallocAsync, hipHostMalloc; lvgpu_malloc included,
+ * the LVGL callbacks of lvgpu_lvgl.h not) -- lvgpu_blend_batch_noalloc must leave it unchanged -- and the launches of
+ * the scan-order pre-pass of the translucent unmasked fill (the one user of that entry point's fixed scratch array). */
+typedef struct {
+    uint64_t alloc_calls;
+    uint64_t first_nonblack_launches;
+    uint64_t band_pad_bytes; /* dynamic LDS the calling thread's last band-kernel launch asked for on top of its 64 KB  */
+                             /* (a residency tuning that is dropped where the device would refuse the sum;           */
+                             /* LVGPU_MAX_LDS_PER_BLOCK in the environment stands in for the device's limit)          */
+} lvgpu_debug_counters_t;
+void lvgpu_debug_counters(lvgpu_debug_counters_t * out);
 
 /* Name of the kernel the last launch on this thread used (diagnostics / tests that assert the fast path ran). */
 const char * lvgpu_last_kernel(void);

@@ -134,7 +134,11 @@ void lvgpu_lvgl_bind(void * lv_draw_sw_init_ctx_fn, void * lv_draw_sw_blend_basi
 void lvgpu_lvgl_set_color_16_swap(int swap);
 
 /*
- * Deferred mode (off by default; read by lvgpu_draw_ctx_init).  LVGL's producers issue one lv_draw_sw_blend per row of
+ * Deferred mode (read by lvgpu_draw_ctx_init).  on = 1: on; 0: off (immediate mode: every blend call is a round trip
+ * to the device, correct anywhere and two orders of magnitude slower than LVGL on a live display); -1, the default:
+ * on for a display whose flush_cb is lvgpu_flush_cb -- the installation INTEGRATION.md shows, where the flush callback
+ * draws what is queued before it looks at the buffer -- and off for a display that keeps a flush_cb of its own, which
+ * has to opt in because it has to cooperate (below).  LVGL's producers issue one lv_draw_sw_blend per row of
  * a rounded, anti-aliased or text object (libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:118-330, lv_draw_sw_letter.c:
  * 246-398) -- a 480x320 widget screen is 800-1600 calls.  With deferred mode on, lvgpu_blend only copies the call's
  * source and mask rectangles into a queue; the queue is drawn as ONE display list (lvgpu_blend_list_batch) when the
@@ -159,6 +163,19 @@ void lvgpu_lvgl_set_color_16_swap(int swap);
  * libraries/lvgl/src/core/lv_refr.c:1262-1296, with no hook in between) stays in immediate mode.
  */
 void lvgpu_lvgl_set_deferred(int on);
+
+/*
+ * What the callbacks do when the GPU fails them (they return void, LVGL has no error channel).  In immediate mode a
+ * failure before the blended rectangle starts to travel back -- no memory for the staging buffers, a refused copy or
+ * launch -- leaves the host buffer untouched: it is counted (lvgpu_lvgl_stats_t.errors and blend_delegated), reported on
+ * stderr the first few times, and the call is drawn by the host program's lv_draw_sw_blend_basic, the convention of
+ * LVGL's GPU back-ends (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130); the program keeps running.
+ * With no lv_draw_sw_blend_basic bound, in deferred mode (the calls that filled the queue have long returned and their
+ * sources are gone) and once a result is on its way back, a failure ends the program with a message: a frame with a
+ * hole in it must not go unnoticed.  lvgpu_lvgl_inject_failure(n) makes the n-th immediate blend from now fail before
+ * it touches the GPU (0 = none): a hook for tests of the above.
+ */
+void lvgpu_lvgl_inject_failure(int nth_blend);
 
 /*
  * Memory for the display's draw buffers (the argument of lv_disp_draw_buf_init): what the port takes from

@@ -403,7 +403,7 @@ static void map_argb(uint8_t * dest, int w, int h, int dest_stride, const uint16
     }
 }
 
-/* lv_draw_sw_blend :95-106 + lv_draw_sw_blend_basic :108-204 (set_px_cb == NULL, antialiasing == 1). */
+/* lv_draw_sw_blend :95-106 + lv_draw_sw_blend_basic :108-204 (set_px_cb == NULL). */
 int lvref_blend(const lvref_blend_t * b)
 {
     if(b->opa <= OPA_MIN) return 0; /* :98 */
@@ -426,6 +426,11 @@ int lvref_blend(const lvref_blend_t * b)
     }
     int mask_stride = 0;
     if(mask) {
+        if(b->antialiasing_off) { /* :150-156: the caller's mask itself is rounded, all of mask_area */
+            uint8_t * m = (uint8_t *)b->mask_buf;
+            int32_t mask_size = (int32_t)aw(&b->mask_area) * ah(&b->mask_area);
+            for(int32_t i = 0; i < mask_size; i++) m[i] = m[i] > 128 ? 255 : 0;
+        }
         mask_stride = aw(&b->mask_area); /* :158-159 */
         mask += (size_t)mask_stride * (a.y1 - b->mask_area.y1) + (a.x1 - b->mask_area.x1);
     }
@@ -497,6 +502,12 @@ void lvref_image_convert(const void * src, int format, uint16_t * color, uint8_t
 int lvref_img_blend(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, lvref_area_t coords, const void * src,
                     int format, uint8_t opa, int swap, int hor_res)
 {
+    return lvref_img_blend_aa(buf, buf_area, clip_area, coords, src, format, opa, swap, hor_res, 0);
+}
+
+int lvref_img_blend_aa(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, lvref_area_t coords, const void * src,
+                       int format, uint8_t opa, int swap, int hor_res, int antialiasing_off)
+{
     lvref_area_t blend_area;
     if(!lvref_area_intersect(&blend_area, &clip_area, &coords)) return 0; /* callers pass clip within coords */
     int src_w = aw(&coords);
@@ -535,6 +546,7 @@ int lvref_img_blend(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, l
         b.mask_area = chunk;
         b.opa = opa;
         b.swap = (uint8_t)swap;
+        b.antialiasing_off = antialiasing_off ? 1 : 0;
         lvref_blend(&b); /* :185 */
         chunk.y1 = (int16_t)(chunk.y2 + 1);
         chunk.y2 = (int16_t)(chunk.y1 + (int)buf_h - 1);

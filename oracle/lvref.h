@@ -57,6 +57,8 @@ typedef struct {
     uint8_t blend_mode;          /* dsc->blend_mode */
     uint8_t swap;                /* LV_COLOR_16_SWAP */
     uint8_t screen_transp;       /* disp->driver->screen_transp (ARGB8565 destination) */
+    uint8_t antialiasing_off;    /* disp->driver->antialiasing == 0: the mask is rounded to 0 / 255, IN PLACE over the
+                                    whole mask_area, before anything else looks at it (:150-156) */
 } lvref_blend_t;
 
 /* lv_draw_sw_blend (:95-106) + lv_draw_sw_blend_basic (:108-204).  Returns 0, or -1 for a mode not restated. */
@@ -74,6 +76,10 @@ void lvref_image_convert(const void * src, int format, uint16_t * color, uint8_t
  * worth of whole rows at a time, one lv_draw_sw_blend per chunk.  coords = image position; src covers coords. */
 int lvref_img_blend(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, lvref_area_t coords, const void * src,
                     int format, uint8_t opa, int swap, int hor_res);
+/* The same on a display with anti-aliasing switched off: every chunk's alpha plane is the mask of its blend and is
+ * rounded there (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:150-156). */
+int lvref_img_blend_aa(void * buf, lvref_area_t buf_area, lvref_area_t clip_area, lvref_area_t coords, const void * src,
+                       int format, uint8_t opa, int swap, int hor_res, int antialiasing_off);
 
 /* ---- flush (src/lv_port.c:428-572) ---- */
 typedef void (*lvref_draw_bitmap_cb)(void * user, int x_start, int y_start, int x_end, int y_end,

@@ -50,6 +50,7 @@ class BlendDsc(C.Structure):
         ("blend_mode", C.c_uint8),
         ("swap", C.c_uint8),
         ("screen_transp", C.c_uint8),
+        ("antialiasing_off", C.c_uint8),
     ]
 
 
@@ -102,6 +103,8 @@ def lib():
                                              C.c_int]
         L.lvref_img_blend.restype = C.c_int
         L.lvref_img_blend.argtypes = [C.c_void_p, Area, Area, Area, C.c_void_p, C.c_int, C.c_uint8, C.c_int, C.c_int]
+        L.lvref_img_blend_aa.restype = C.c_int
+        L.lvref_img_blend_aa.argtypes = [C.c_void_p, Area, Area, Area, C.c_void_p, C.c_int, C.c_uint8, C.c_int, C.c_int, C.c_int]
         L.lvref_flush.restype = C.c_int
         L.lvref_flush.argtypes = [C.POINTER(Area), C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p]
@@ -122,8 +125,9 @@ def _p(a):
 
 
 def blend(buf, buf_area, clip_area, blend_area, src=None, color=0, mask=None, mask_res=MASK_RES_CHANGED,
-          mask_area=None, opa=255, blend_mode=0, swap=1, screen_transp=0):
-    """In-place lv_draw_sw_blend on one numpy frame (uint16 HxW, or uint8 HxWx3 for screen_transp)."""
+          mask_area=None, opa=255, blend_mode=0, swap=1, screen_transp=0, antialiasing=1):
+    """In-place lv_draw_sw_blend on one numpy frame (uint16 HxW, or uint8 HxWx3 for screen_transp).  With
+    antialiasing=0 the mask array is rounded in place as well, as the reference does (lv_draw_sw_blend.c:150-156)."""
     assert buf.flags.c_contiguous
     d = BlendDsc()
     d.buf = _p(buf)
@@ -139,6 +143,7 @@ def blend(buf, buf_area, clip_area, blend_area, src=None, color=0, mask=None, ma
     d.blend_mode = blend_mode
     d.swap = swap
     d.screen_transp = screen_transp
+    d.antialiasing_off = 0 if antialiasing else 1
     return lib().lvref_blend(C.byref(d))
 
 
@@ -160,9 +165,9 @@ def image_convert(src, fmt, swap, chroma_keyed=0, chroma_key=0, recolor=0, recol
     return color, alpha
 
 
-def img_blend(buf, buf_area, clip_area, coords, src, fmt, opa, swap, hor_res):
-    return lib().lvref_img_blend(_p(buf), Area.of(buf_area), Area.of(clip_area), Area.of(coords), _p(src), fmt,
-                                 int(opa), swap, hor_res)
+def img_blend(buf, buf_area, clip_area, coords, src, fmt, opa, swap, hor_res, antialiasing=1):
+    return lib().lvref_img_blend_aa(_p(buf), Area.of(buf_area), Area.of(clip_area), Area.of(coords), _p(src), fmt,
+                                    int(opa), swap, hor_res, 0 if antialiasing else 1)
 
 
 _CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16))
@@ -298,8 +303,12 @@ def ref(swap=1):
                                         C.c_int, C.c_int]
         L.ref_scene_fb.restype = C.c_void_p
         L.ref_scene_draw_buf.restype = C.c_void_p
+        if hasattr(L, "ref_scene_draw_buf_act"):
+            L.ref_scene_draw_buf_act.restype = C.c_void_p
         L.ref_scene_drv.restype = C.c_void_p
         L.ref_scene_build.argtypes = [C.c_int]
+        if hasattr(L, "ref_set_antialiasing"):
+            L.ref_set_antialiasing.argtypes = [C.c_int]
         if hasattr(L, "ref_scene_set_pre_flush"):
             L.ref_scene_set_pre_flush.argtypes = [C.c_void_p]
         if hasattr(L, "ref_scene_set_buf_allocator"):

@@ -112,6 +112,11 @@ REF_API void ref_blend(void * buf, const int16_t * buf_area, const int16_t * cli
     g_drv0.screen_transp = 0;
 }
 
+/* disp->driver->antialiasing of the display ref_blend and ref_img_decoded draw on (default 1,
+ * libraries/lvgl/src/hal/lv_hal_disp.c:94); 0 makes lv_draw_sw_blend_basic round every mask in place
+ * (libraries/lvgl/src/draw/sw/lv_draw_sw_blend.c:150-156). */
+REF_API void ref_set_antialiasing(int on) { g_drv0.antialiasing = on ? 1 : 0; }
+
 /* lv_draw_sw_img_decoded (libraries/lvgl/src/draw/sw/lv_draw_sw_img.c:44): exercises convert_cb (:203-298)
  * and the <= hor_res pixel chunking (:109-191) in front of the blend. */
 REF_API void ref_img_decoded(void * buf, const int16_t * buf_area, const int16_t * clip_area, const int16_t * coords,
@@ -338,6 +343,7 @@ static lv_disp_draw_buf_t g_dbuf1;
 static lv_disp_drv_t g_drv1;
 static lv_disp_t * g_disp1;
 static lv_color_t * g_buf1;
+static lv_color_t * g_buf1b; /* second draw buffer (flags bit 6: lv_disp_draw_buf_init with a buf2), or NULL */
 static lv_color_t * g_fb1; /* captured by capture_flush */
 static int g_fb_w, g_fb_h;
 static int g_flush_calls;
@@ -398,6 +404,11 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
         g_disp1 = NULL;
         if(g_buf1_free) g_buf1_free(g_buf1);
         else free(g_buf1);
+        if(g_buf1b) {
+            if(g_buf1_free) g_buf1_free(g_buf1b);
+            else free(g_buf1b);
+            g_buf1b = NULL;
+        }
         free(g_fb1);
     }
     g_fb_w = hor_res;
@@ -413,9 +424,15 @@ REF_API int ref_scene_display(int hor_res, int ver_res, void * init, void * dein
         g_buf1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
         g_buf1_free = NULL;
     }
+    if(flags & 64) { /* two draw buffers that LVGL alternates between (libraries/lvgl/src/hal/lv_hal_disp.c:150-158) */
+        const size_t bytes = (size_t)hor_res * ver_res * (size_t)g_px_bytes;
+        g_buf1b = g_buf1_free ? g_buf_alloc(bytes) : malloc(bytes);
+        if(!g_buf1b) return -1;
+        memset(g_buf1b, 0, bytes);
+    }
     g_fb1 = calloc((size_t)hor_res * ver_res, (size_t)g_px_bytes);
     g_flush_calls = 0;
-    lv_disp_draw_buf_init(&g_dbuf1, g_buf1, NULL, (uint32_t)hor_res * ver_res);
+    lv_disp_draw_buf_init(&g_dbuf1, g_buf1, g_buf1b, (uint32_t)hor_res * ver_res);
     lv_disp_drv_init(&g_drv1);
     g_drv1.hor_res = (lv_coord_t)hor_res;
     g_drv1.ver_res = (lv_coord_t)ver_res;
@@ -448,6 +465,10 @@ REF_API void * ref_scene_fb(void)
 REF_API void * ref_scene_draw_buf(void)
 {
     return g_buf1;
+}
+REF_API void * ref_scene_draw_buf_act(void) /* the buffer LVGL drew the last refresh into */
+{
+    return g_dbuf1.buf_act;
 }
 REF_API int ref_scene_px_bytes(void)
 {

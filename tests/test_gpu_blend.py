@@ -304,53 +304,66 @@ def test_translucent_fill_many_frames_one_block_per_frame(gpu, oracle, swap):
         assert bad.size == 0, "frames %s differ" % bad[:8]
 
 
-@pytest.mark.parametrize("span", [None, 8, 16, 64])
-def test_blend_rects_owning_their_rows(gpu, oracle, span, monkeypatch):
-    """LVGPU_BLEND_FLAG_OWNS_ROWS: the rows of a clipped area are written in whole aligned pieces (64 bytes; the
-    LVGPU_ROWS_SPAN switch covers the other sizes the kernel takes).  Same pixels as without the flag, whatever the
-    buffer width, the alignment of the batch inside its allocation and the source kind -- and nothing is written
-    outside the buffer rows the area touches: the batch sits inside a larger allocation whose other bytes must keep
-    their sentinel, and rows above and below the area must keep theirs."""
-    import torch
-    if span is not None:
-        monkeypatch.setenv("LVGPU_ROWS_SPAN", str(span))
-    rng = np.random.default_rng(500 + (span or 0))
-    for t in range(160):
-        swap = int(rng.integers(0, 2))
-        W = int(rng.choice([67, 96, 100, 128, 200, 33, 9]))
-        H, N = int(rng.integers(1, 12)), int(rng.integers(1, 4))
-        buf_area = (0, 0, W - 1, H - 1)
-        x1, y1 = int(rng.integers(0, W)), int(rng.integers(0, H))
-        x2, y2 = int(rng.integers(x1, W)), int(rng.integers(y1, H))
-        if t % 5 == 0:
-            x1, x2 = 0, W - 1                                # whole rows: both ends clamp at the buffer row
-        ba = (x1, y1, x2, y2)
-        bw, bh = x2 - x1 + 1, y2 - y1 + 1
-        fmt = int(rng.choice([0, 1, 1, 2, 4]))
+@pytest.mark.parametrize("swap", [1, 0])
+def test_blend_without_antialiasing(gpu, oracle, swap):
+    """LVGPU_BLEND_FLAG_NO_AA = a display with anti-aliasing off: every mask value (and the alpha of a source with its
+    own alpha) is rounded to 0 / 255 before the blend (lv_draw_sw_blend.c:150-156).  Against the oracle -- itself pinned
+    on the real LVGL for this case (tests/golden/aa_off_swap*.npz) -- through the clipped-area kernel, the contiguous
+    kernels, both destination formats, single calls and display lists; masks crowd the threshold (127, 128, 129)."""
+    rng = np.random.default_rng(900 + swap)
+
+    def mask_of(shape):
+        m = rand_mask(rng, shape)
+        sel = rng.random(shape)
+        m[sel < 0.25] = rng.integers(126, 131, int((sel < 0.25).sum()), dtype=np.uint8)
+        return m
+
+    for t in range(120):
+        transp = int(t % 3 == 2)
+        W, H = ((67, 19), (64, 64), (96, 8))[t % 3 if not transp else t % 2]
+        N = 3
+        full = (0, 0, W - 1, H - 1)
+        if t % 2:
+            ba = full                                          # whole buffer: the contiguous kernels
+        else:
+            x1, y1 = int(rng.integers(0, W - 8)), int(rng.integers(0, H - 2))
+            ba = (x1, y1, int(rng.integers(x1 + 1, W)), int(rng.integers(y1 + 1, H)))
+        bw, bh = ba[2] - ba[0] + 1, ba[3] - ba[1] + 1
+        fmt = int(rng.choice([0, 1, 2, 4]))
+        opa = int(rng.choice([255, 254, 253, 200]))
+        mode = int(rng.choice([0, 0, 1, 3])) if fmt in (0, 1) else 0
+        color = int(rng.integers(0, 65536))
         src = mask = None
         if fmt == 1:
             src = rng.integers(0, 65536, (N, bh, bw), dtype=np.uint16)
         elif fmt == 2:
-            src = rng.integers(0, 1 << 32, (N, bh, bw), dtype=np.uint32)
+            src = (rng.integers(0, 1 << 24, (N, bh, bw), dtype=np.uint32)) | (mask_of((N, bh, bw)).astype(np.uint32) << 24)
         elif fmt == 4:
             src = rng.integers(0, 256, (N, bh, bw, 3), dtype=np.uint8)
-        if fmt in (0, 1) and rng.random() < 0.7:
-            mask = rand_mask(rng, (N, bh, bw))
-        opa = int(rng.choice([255, 255, 200, 137, 3]))
-        color = int(rng.integers(0, 65536))
-        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
-        if t % 4 == 0:
-            dst[:, : H // 2 + 1] = 0
-        exp = _oracle_frames(oracle, dst, buf_area, buf_area, ba, src, color, mask, 2, ba, opa, 0, swap, fmt=fmt, hor_res=W)
-        off = int(rng.choice([0, 0, 1, 3, 4, 8, 13]))        # pixels in front of the batch inside its allocation
-        base = torch.full((off + N * H * W + 64,), 0x5A5A, dtype=torch.int16, device="cuda")
-        d = base[off:off + N * H * W].view(N, H, W)
-        d.copy_(to_dev(dst))
-        dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color,
-                           mask_buf=None if mask is None else to_dev(mask), opa=opa, src_format=fmt if fmt else None,
-                           flags=gpu.FLAG_OWNS_ROWS)
-        gpu.lv_draw_sw_blend(gpu.DrawCtx(d, buf_area, buf_area, color_16_swap=swap), dsc)
-        got = to_np(d, np.uint16)
-        assert np.array_equal(got, exp), (t, W, H, ba, fmt, opa, off, gpu.last_kernel())
-        whole = to_np(base, np.uint16)
-        assert (whole[:off] == 0x5A5A).all() and (whole[off + N * H * W:] == 0x5A5A).all(), (t, "outside the batch")
+            src[..., 2] = mask_of((N, bh, bw))
+        if fmt in (0, 1):
+            mask = mask_of((N, bh, bw))
+        if transp and fmt in (2, 4):
+            fmt, src, mask = 0, None, mask_of((N, bh, bw))     # the reference draws such images through convert_cb first
+        dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8) if transp else rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        exp = dst.copy()
+        for f in range(N):
+            if fmt in (0, 1):
+                oracle.blend(exp[f], full, full, ba, src=None if src is None else src[f], color=color,
+                             mask=None if mask is None else mask[f].copy(), opa=opa, blend_mode=mode, swap=swap,
+                             screen_transp=transp, antialiasing=0)
+            else:
+                oracle.img_blend(exp[f], full, full, ba, np.ascontiguousarray(src[f]), fmt, opa, swap, 480, antialiasing=0)
+        d = to_dev(dst)
+        m_dev = None if mask is None else to_dev(mask)
+        ctx = gpu.DrawCtx(d, full, full, color_16_swap=swap, screen_transp=transp)
+        dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color, mask_buf=m_dev, opa=opa,
+                           blend_mode=mode, src_format=fmt if fmt else None, flags=gpu.FLAG_NO_AA)
+        if t % 4 < 2:
+            gpu.lv_draw_sw_blend(ctx, dsc)
+        else:
+            gpu.blend_list(ctx, [dsc])
+        got = to_np(d, np.uint8 if transp else np.uint16).reshape(exp.shape)
+        assert np.array_equal(got, exp), (t, W, H, ba, fmt, opa, mode, transp, gpu.last_kernel())
+        if mask is not None:
+            assert np.array_equal(to_np(m_dev, np.uint8).reshape(mask.shape), mask), "the caller's mask is left as it is"

@@ -303,3 +303,75 @@ def test_discard_dst_is_for_the_fused_call_only(gpu):
     h = to_np(d2, np.uint16)
     assert (h[0, :8, :8] == 0x1234).all() and (h[0, 8:] == 0).all()
     assert (to_np(out, np.uint16).reshape(16, 16)[:8, 8:] == 0x1234).all()
+
+
+@pytest.mark.parametrize("rot", [1, 3, 2])
+@pytest.mark.parametrize("shape,fmt", [((64, 64), 2), ((128, 64), 1), ((100, 37), 4), ((480, 328), 2), ((72, 40), 0)])
+def test_blend_flush_without_antialiasing(gpu, oracle, rot, shape, fmt):
+    """LVGPU_BLEND_FLAG_NO_AA through the fused blend + flush kernels (tile, band, column, any-size, linear)."""
+    W, H = shape
+    N = 2
+    rng = np.random.default_rng(W + H + rot + fmt)
+    area = (0, 0, W - 1, H - 1)
+    for swap in (1, 0):
+        dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        color = int(rng.integers(0, 65536))
+        near = lambda shp: rng.integers(120, 137, shp, dtype=np.uint8)  # noqa: E731  around the threshold
+        src = mask = None
+        if fmt == 1:
+            src, mask = rng.integers(0, 65536, (N, H, W), dtype=np.uint16), near((N, H, W))
+        elif fmt == 2:
+            src = rng.integers(0, 1 << 24, (N, H, W), dtype=np.uint32) | (near((N, H, W)).astype(np.uint32) << 24)
+        elif fmt == 4:
+            src = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+            src[..., 2] = near((N, H, W))
+        else:
+            mask = near((N, H, W))
+        exp = dst.copy()
+        for f in range(N):
+            if fmt in (2, 4):
+                oracle.img_blend(exp[f], area, area, area, np.ascontiguousarray(src[f]), fmt, 255, swap, W, antialiasing=0)
+            else:
+                oracle.blend(exp[f], area, area, area, src=None if src is None else src[f], color=color, mask=mask[f].copy(),
+                             opa=255, swap=swap, antialiasing=0)
+        d = to_dev(dst)
+        dsc = gpu.BlendDsc(area, src_buf=None if src is None else to_dev(src), color=color,
+                           mask_buf=None if mask is None else to_dev(mask), opa=255, src_format=fmt if fmt else None,
+                           flags=gpu.FLAG_NO_AA)
+        out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
+        assert "fused" in gpu.last_kernel() or (rot == 2 and (W * H) % 8)   # a half turn off the 8-pixel grid: two passes
+        assert np.array_equal(to_np(d, np.uint16), exp), (swap, gpu.last_kernel())
+        got = to_np(out, np.uint16).reshape(N, -1)
+        for f in range(N):
+            assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 1 - swap)), (swap, f)
+
+
+def test_band_kernel_without_its_residency_pad(gpu, oracle, monkeypatch):
+    """k_band asks for dynamic LDS it never touches so that one workgroup has a CU to itself; on a device (or runtime)
+    that allows a workgroup no more than the kernel's own 64 KB the pad is left out and the launch goes ahead."""
+    import ctypes as C
+    from vvc_amd import _lib
+    W, H, N = 200, 96, 3
+    rng = np.random.default_rng(77)
+    area = (0, 0, W - 1, H - 1)
+    dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+    src = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+    mask = rand_mask(rng, (N, H, W))
+    exp = dst.copy()
+    for f in range(N):
+        oracle.blend(exp[f], area, area, area, src=src[f], mask=mask[f], opa=255, swap=1)
+    pads = []
+    for limit in (None, 65536):
+        if limit:
+            monkeypatch.setenv("LVGPU_MAX_LDS_PER_BLOCK", str(limit))
+        d = to_dev(dst)
+        out = gpu.blend_flush(gpu.DrawCtx(d), gpu.BlendDsc(area, src_buf=to_dev(src), mask_buf=to_dev(mask), opa=255), 1)
+        assert gpu.last_kernel() == "k_band(fused)"
+        c = _lib.DebugCounters()
+        _lib.lib().lvgpu_debug_counters(C.byref(c))
+        pads.append(int(c.band_pad_bytes))
+        assert np.array_equal(to_np(d, np.uint16), exp)
+        got = to_np(out, np.uint16).reshape(N, -1)
+        for f in range(N):
+            assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, 1, 0))
+    assert pads[1] == 0 and pads[0] in (0, 40 * 1024)   # 0 on a stream confined to some CUs or with LVGPU_NO_RESIDENCY_CAP

@@ -206,3 +206,89 @@ def test_repeated_refreshes_replay_the_plan(world, oracle, flush, flags, request
     assert replays[4] == replays[3] == replays[5] - 0 or replays[5] == replays[4]
     assert replays[7] > replays[6] > replays[5]
     R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+
+
+def test_two_draw_buffers_still_replay(world, request):
+    """A display with two draw buffers (lv_disp_draw_buf_init with a buf2, libraries/lvgl/src/hal/lv_hal_disp.c:150-158)
+    alternates between them from refresh to refresh; the plan compiled for one is replayed over the other."""
+    swap, R, L = world
+    if not request.node.callspec.params["world"][1]:
+        pytest.skip("deferred mode only")
+    w, h = 480, 320
+    sw = _render_sw(R, w, h, 2)
+    L.lvgpu_lvgl_reset_stats()
+    assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                               None, None, 1, 64) == 0
+    st = Stats()
+    bufs = set()
+    for _ in range(6):
+        R.ref_scene_build(2)
+        R.ref_scene_refresh()
+        assert np.array_equal(_fb(R, w, h), sw)
+        bufs.add(R.ref_scene_draw_buf_act())
+    L.lvgpu_lvgl_get_stats(C.byref(st))
+    assert len(bufs) == 2, "LVGL is expected to alternate between the two buffers"
+    assert st.errors == 0 and st.list_replays >= 4          # refresh 1 plans, 2 compiles + replays, 3.. replay
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+
+
+def test_immediate_mode_survives_a_gpu_failure(world, request):
+    """Immediate mode: a blend that fails before anything has come back from the GPU is counted, drawn by the host's
+    lv_draw_sw_blend_basic (the convention of LVGL's GPU back-ends, stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130) and the
+    refresh goes on; the frame is still LVGL's own."""
+    swap, R, L = world
+    if request.node.callspec.params["world"][1]:
+        pytest.skip("immediate mode only")
+    for flags in (0, 1, 2):                                  # plain, anti-aliasing off, transparent screen
+        w, h = 320, 240
+        sw = _render_sw(R, w, h, 2, flags)
+        L.lvgpu_lvgl_reset_stats()
+        assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                                   None, None, 1, flags) == 0
+        R.ref_scene_build(2)
+        L.lvgpu_lvgl_inject_failure(40)                      # the 40th blend of the refresh
+        R.ref_scene_refresh()
+        L.lvgpu_lvgl_inject_failure(0)
+        st = Stats()
+        L.lvgpu_lvgl_get_stats(C.byref(st))
+        assert st.errors == 1 and st.blend_delegated == 1 and st.blend_gpu > 100
+        assert np.array_equal(_fb(R, w, h), sw), flags
+    R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+
+
+def test_deferred_by_default_behind_lvgpu_flush_cb(world, oracle, request):
+    """lvgpu_lvgl_set_deferred(-1), the library's default: a display flushed by lvgpu_flush_cb queues its blends (that
+    callback draws the queue before it looks at the buffer); a display with a flush_cb of its own stays immediate."""
+    swap, R, L = world
+    if request.node.callspec.params["world"][1] != 0:
+        pytest.skip("once is enough")
+    w, h = 480, 320
+    sw = _render_sw(R, w, h, 1)
+    chunks = []
+
+    def sink(_user, xs, ys, xe, ye, data):
+        chunks.append(np.ctypeslib.as_array(data, shape=((xe - xs) * (ye - ys),)).copy())
+
+    cb = DRAW_BITMAP(sink)
+    cfg = FlushCfg(1, w * h // 10, 0, C.cast(cb, C.c_void_p), None, None)
+    L.lvgpu_lvgl_set_deferred(-1)
+    try:
+        st = Stats()
+        for own_flush in (False, True):
+            L.lvgpu_lvgl_reset_stats()
+            assert R.ref_scene_display(w, h, _addr(L.lvgpu_draw_ctx_init), _addr(L.lvgpu_draw_ctx_deinit), L.lvgpu_draw_ctx_size(),
+                                       None if own_flush else _addr(L.lvgpu_flush_cb), None if own_flush else C.addressof(cfg),
+                                       1, 0) == 0
+            del chunks[:]
+            R.ref_scene_build(1)
+            R.ref_scene_refresh()
+            L.lvgpu_lvgl_get_stats(C.byref(st))
+            if own_flush:
+                assert st.blend_lists == 0 and st.blend_gpu > 100
+                assert np.array_equal(_fb(R, w, h), sw)
+            else:
+                assert 1 <= st.blend_lists <= 4 and st.blend_gpu > 100 * st.blend_lists
+                assert np.array_equal(np.concatenate(chunks[-10:]), oracle.flush_frame(sw, w, h, 1, 0))
+    finally:
+        R.ref_scene_display(16, 16, None, None, 0, None, None, 1, 0)
+        L.lvgpu_lvgl_set_deferred(0)

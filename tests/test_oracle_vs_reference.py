@@ -147,3 +147,54 @@ def test_image_convert_recolor_chroma_key(oracle, ref):
                 mask = None if cf == 4 else alpha.reshape(ih, iw)
                 oracle.blend(d2, area, area, coords, src=color.reshape(ih, iw), mask=mask, opa=opa, swap=swap)
                 assert np.array_equal(d1, d2), (cf, recolor_opa, opa)
+
+
+def test_fuzz_blend_without_antialiasing(oracle, ref):
+    """disp->driver->antialiasing == 0: lv_draw_sw_blend_basic rounds the caller's mask in place over the whole
+    mask_area (lv_draw_sw_blend.c:150-156) -- draw buffer AND mask must come out as LVGL leaves them, for RGB565 and
+    ARGB8565 destinations; a TRUE_COLOR_ALPHA image has its alpha plane rounded chunk by chunk."""
+    swap, L = ref
+    rng = np.random.default_rng(70 + swap)
+    W, H = 67, 9
+    full = (0, 0, W - 1, H - 1)
+    L.ref_set_antialiasing(0)
+    try:
+        for t in range(3000):
+            transp = int(t % 3 == 0)
+            buf = rng.integers(0, 256, (H, W, 3), dtype=np.uint8) if transp else rng.integers(0, 65536, (H, W), dtype=np.uint16)
+            x1, y1 = int(rng.integers(-3, W - 2)), int(rng.integers(-2, H - 1))
+            x2, y2 = int(rng.integers(x1, W + 3)), int(rng.integers(y1, H + 2))
+            cx1, cy1 = int(rng.integers(0, W)), int(rng.integers(0, H))
+            clip = (cx1, cy1, int(rng.integers(cx1, W)), int(rng.integers(cy1, H)))
+            bw, bh = x2 - x1 + 1, y2 - y1 + 1
+            src = rng.integers(0, 65536, (bh, bw), dtype=np.uint16) if rng.random() < 0.5 else None
+            ma = (x1 - int(rng.integers(0, 3)), y1 - int(rng.integers(0, 3)), x2 + int(rng.integers(0, 3)),
+                  y2 + int(rng.integers(0, 3)))
+            mask = rng.integers(120, 137, (ma[3] - ma[1] + 1, ma[2] - ma[0] + 1), dtype=np.uint8) if t % 2 else \
+                rand_mask(rng, (ma[3] - ma[1] + 1, ma[2] - ma[0] + 1))
+            opa = int(rng.choice(OPAS))
+            mres = int(rng.choice([1, 2, 2, 2, 3]))
+            color = int(rng.integers(0, 65536))
+            mode = int(rng.choice([0, 0, 0, 1, 2, 3]))
+            b1, b2 = buf.copy(), buf.copy()
+            m1, m2 = mask.copy(), mask.copy()
+            L.ref_blend(oracle._p(b1), oracle._p(oracle._area16(full)), oracle._p(oracle._area16(clip)),
+                        oracle._p(oracle._area16((x1, y1, x2, y2))), oracle._p(src), color, oracle._p(m1), mres,
+                        oracle._p(oracle._area16(ma)), opa, mode, transp)
+            oracle.blend(b2, full, clip, (x1, y1, x2, y2), src=src, color=color, mask=m2, mask_res=mres, mask_area=ma, opa=opa,
+                         blend_mode=mode, swap=swap, screen_transp=transp, antialiasing=0)
+            assert np.array_equal(b1, b2), (t, opa, mres, mode, transp)
+            assert np.array_equal(m1, m2), (t, "mask as the call leaves it")
+        for t in range(200):
+            buf = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+            co = (int(rng.integers(0, 10)), int(rng.integers(0, 3)), int(rng.integers(30, W)), int(rng.integers(4, H)))
+            clip = (co[0] + int(rng.integers(0, 3)), co[1], co[2] - int(rng.integers(0, 3)), co[3])
+            src = rng.integers(0, 256, (co[3] - co[1] + 1, co[2] - co[0] + 1, 3), dtype=np.uint8)
+            opa = int(rng.choice([255, 254, 253, 128]))
+            b1, b2 = buf.copy(), buf.copy()
+            L.ref_img_decoded(oracle._p(b1), oracle._p(oracle._area16(full)), oracle._p(oracle._area16(clip)),
+                              oracle._p(oracle._area16(co)), oracle._p(src), 5, opa, 0, 0, 0)
+            oracle.img_blend(b2, full, clip, co, src, 4, opa, swap, 480, antialiasing=0)
+            assert np.array_equal(b1, b2), (t, opa)
+    finally:
+        L.ref_set_antialiasing(1)

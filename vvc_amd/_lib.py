@@ -135,8 +135,11 @@ def lib():
         "lvgpu_stream_create": (C.c_int, [C.POINTER(vp)]),
         "lvgpu_stream_destroy": (C.c_int, [vp]),
         "lvgpu_xcc_census": (C.c_int, [vp, C.c_int, vp]),
+        "lvgpu_debug_counters": (None, [C.POINTER(DebugCounters)]),
         "lvgpu_lvgl_bind": (None, [vp, vp, vp]),
         "lvgpu_lvgl_set_color_16_swap": (None, [C.c_int]),
+        "lvgpu_lvgl_set_deferred": (None, [C.c_int]),
+        "lvgpu_lvgl_inject_failure": (None, [C.c_int]),
         "lvgpu_draw_ctx_init": (None, [vp, vp]),
         "lvgpu_draw_ctx_deinit": (None, [vp, vp]),
         "lvgpu_draw_ctx_size": (sz, []),
@@ -171,6 +174,11 @@ class ImageOpts(C.Structure):
     """lvgpu_image_opts_t"""
     _fields_ = [("chroma_keyed", C.c_int32), ("chroma_key", C.c_uint16), ("recolor", C.c_uint16), ("recolor_opa", C.c_uint8),
                 ("reserved", C.c_uint8 * 3)]
+
+
+class DebugCounters(C.Structure):
+    """lvgpu_debug_counters_t"""
+    _fields_ = [("alloc_calls", C.c_uint64), ("first_nonblack_launches", C.c_uint64), ("band_pad_bytes", C.c_uint64)]
 
 
 class FlushChunk(C.Structure):

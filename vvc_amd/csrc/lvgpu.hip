@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -27,6 +28,7 @@ namespace {
 
 thread_local std::string g_err;
 thread_local const char * g_last_kernel = "";
+std::atomic<uint64_t> g_alloc_calls{0}, g_first_nb_launches{0};  // lvgpu_debug_counters
 
 int fail(int code, const char * fmt, ...)
 {
@@ -105,21 +107,11 @@ int scratch_on_current_device(uint32_t ** out)
 
 enum Resolve { R_NOOP = 0, R_WORK = 1 };
 
-// Pixels per whole piece under LVGPU_BLEND_FLAG_OWNS_ROWS: 32 (64 bytes, the unit in which the L2 writes to memory).
-// LVGPU_ROWS_SPAN=8|16|32|64 in the environment (read at every call) changes it: a switch for measuring.
-int rows_span_px()
-{
-    if(const char * e = getenv("LVGPU_ROWS_SPAN")) {
-        const int v = atoi(e);
-        if(v == 8 || v == 16 || v == 32 || v == 64) return v;
-    }
-    return 32;
-}
-
 // lv_draw_sw_blend (:95-106) + lv_draw_sw_blend_basic (:108-204) up to the fill_normal/map_normal dispatch.
 // Returns R_NOOP / R_WORK or a negative error; on R_WORK `a` describes the clipped area.
 int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & area, unsigned allowed_flags = 0)
 {
+    allowed_flags |= LVGPU_BLEND_FLAG_NO_AA;
     memset(&a, 0, sizeof(a));
     if(d == nullptr) return fail(LVGPU_ERR_ARG, "descriptor is NULL");
     if(d->n_frames < 0) return fail(LVGPU_ERR_ARG, "n_frames < 0");
@@ -175,14 +167,11 @@ int resolve_blend(const lvgpu_blend_batch_t * d, BlendArgs & a, lvgpu_area_t & a
         a.mask_fs = d->mask_frame_stride;
         a.mask = mask + (size_t)a.mask_stride * (area.y1 - d->mask_area.y1) + (area.x1 - d->mask_area.x1);   // :159
     }
-    if(d->flags & LVGPU_BLEND_FLAG_OWNS_ROWS) {
-        a.span_px = rows_span_px();
-        a.row_x0 = area.x1 - d->buf_area.x1;
-    }
     a.color = a.swap ? bswap16(d->color) : d->color;
     a.raw_opa = d->opa;
     a.raw_mode = d->blend_mode;
     a.has_mask = masked ? 1 : 0;
+    a.no_aa = (masked && (d->flags & LVGPU_BLEND_FLAG_NO_AA)) ? 1 : 0;                // :150-156
     if(d->dst_argb8565) {  // :177-184: fill_argb / map_argb whatever the blend mode
         a.dst = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(d->dst) +
                 ((size_t)a.dst_stride * (area.y1 - d->buf_area.y1) + (area.x1 - d->buf_area.x1)) * 3);   // :129-133
@@ -234,6 +223,7 @@ int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** owned, uint32_t 
     if(pm_black == a.pf.first_res) return LVGPU_OK;
     uint32_t * buf = provided;
     if(buf == nullptr) {
+        g_alloc_calls++;
         HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&buf), (size_t)a.n_frames * sizeof(uint32_t), st));
         *owned = buf;
     }
@@ -248,6 +238,7 @@ int prepare_first_nb(BlendArgs & a, hipStream_t st, uint32_t ** owned, uint32_t 
         dim3 grid((area + seg_px - 1) / seg_px, std::min<uint32_t>(a.n_frames, 65535));
         hipLaunchKernelGGL(k_first_nonblack, grid, dim3(256), 0, st, a.dst, a.dst_fs, a.dst_stride, a.w, a.h, a.n_frames, seg_px, buf);
         e = hipGetLastError();
+        g_first_nb_launches++;
     }
     if(e != hipSuccess) {
         if(*owned) (void)hipFreeAsync(*owned, st);
@@ -538,6 +529,7 @@ struct ListBuilder {
         it.pf = a.pf;
         it.raw_mode = a.raw_mode;
         it.has_mask = a.has_mask;
+        it.no_aa = a.no_aa;
         if(argb) {
             it.opa = (uint32_t)a.raw_opa;
             // fill_argb's opaque masked loop reads row y of the area at mask[y*w + x] (lv_draw_sw_blend.c:494-505)
@@ -620,6 +612,7 @@ struct ListStaging {
             host = nullptr;
             cap = 0;
             const size_t want = std::max<size_t>(bytes * 2, 1 << 20);
+            g_alloc_calls++;
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&host), want, hipHostMallocPortable));
             cap = want;
         }
@@ -813,6 +806,7 @@ int launch_list(ListBuilder & lb, uint16_t * dst, long long dst_fs, uint32_t n_f
     int rc_stage = g_stage.acquire(blob_bytes, &host);
     if(rc_stage != LVGPU_OK) return rc_stage;
     uint8_t * dev = nullptr;
+    g_alloc_calls++;
     HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&dev), blob_bytes, st));
     ListArgs a;
     memset(&a, 0, sizeof(a));
@@ -879,7 +873,6 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     if(geom->dst == nullptr) return fail(LVGPU_ERR_ARG, "dst is NULL");
 
     // resolve everything first: nothing is launched when any item is malformed
-    const bool argb_list = geom->dst_argb8565 != 0;
     std::vector<BlendArgs> ra((size_t)n_items);
     std::vector<lvgpu_area_t> areas((size_t)n_items);
     std::vector<int> res((size_t)n_items);
@@ -889,11 +882,7 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
            memcmp(&d.buf_area, &geom->buf_area, sizeof(lvgpu_area_t)) != 0 || (d.color_16_swap != 0) != (geom->color_16_swap != 0) ||
            (d.dst_argb8565 != 0) != (geom->dst_argb8565 != 0))
             return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
-        res[i] = resolve_blend(&d, ra[i], areas[i], LVGPU_BLEND_FLAG_OWNS_ROWS);
-        if(res[i] >= 0 && !argb_list) {  // a list owns its buffers: items run on their own may write whole pieces of their rows
-            ra[i].span_px = rows_span_px();
-            ra[i].row_x0 = areas[i].x1 - geom->buf_area.x1;
-        }
+        res[i] = resolve_blend(&d, ra[i], areas[i]);
         if(res[i] < 0) {
             g_err = "item " + std::to_string(i) + ": " + g_err;
             return res[i];
@@ -1021,6 +1010,7 @@ int lvgpu_init(int device)
 int lvgpu_malloc(void ** p, size_t bytes)
 {
     if(!p) return fail(LVGPU_ERR_ARG, "NULL out pointer");
+    g_alloc_calls++;
     HIP_TRY(hipMalloc(p, bytes));
     return LVGPU_OK;
 }
@@ -1055,7 +1045,7 @@ int lvgpu_blend_batch(const lvgpu_blend_batch_t * d, void * stream)
     BlendArgs a;
     lvgpu_area_t area;
     g_last_kernel = "";
-    int r = resolve_blend(d, a, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
+    int r = resolve_blend(d, a, area);
     if(r <= 0) return r;
     return launch_blend(a, d->src_format, (hipStream_t)stream, d->dst_argb8565 != 0);
 }
@@ -1068,7 +1058,7 @@ int lvgpu_blend_batch_noalloc(const lvgpu_blend_batch_t * d, void * stream)
     if(d != nullptr && d->n_frames > LVGPU_NOALLOC_MAX_FRAMES)
         return fail(LVGPU_ERR_ARG, "lvgpu_blend_batch_noalloc takes at most %d frames per call (%d given); split the batch or use "
                     "lvgpu_blend_batch", LVGPU_NOALLOC_MAX_FRAMES, d->n_frames);
-    int r = resolve_blend(d, a, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
+    int r = resolve_blend(d, a, area);
     if(r <= 0) return r;
     uint32_t * buf = nullptr;
     r = scratch_on_current_device(&buf);
@@ -1099,7 +1089,7 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
     hipStream_t st = (hipStream_t)stream;
     BlendArgs a;
     lvgpu_area_t area;
-    int r = resolve_blend(&d->blend, a, area, LVGPU_BLEND_FLAG_DISCARD_DST | LVGPU_BLEND_FLAG_OWNS_ROWS);
+    int r = resolve_blend(&d->blend, a, area, LVGPU_BLEND_FLAG_DISCARD_DST);
     if(r < 0) return r;
     const lvgpu_blend_batch_t & b = d->blend;
     const int W = aw(b.buf_area), H = ah(b.buf_area);
@@ -1209,7 +1199,7 @@ int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_
             return fail(LVGPU_ERR_ARG, "item %d does not address the same batch of buffers as the list", i);
         BlendArgs ra;
         lvgpu_area_t area;
-        int r = resolve_blend(&d, ra, area, LVGPU_BLEND_FLAG_OWNS_ROWS);
+        int r = resolve_blend(&d, ra, area);
         if(r < 0) {
             g_err = "item " + std::to_string(i) + ": " + g_err;
             return r;
@@ -1228,6 +1218,7 @@ int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_
     const size_t bytes = pack_tables(plan, lb, nullptr, nullptr, nullptr);
     std::vector<uint8_t> host(bytes);
     hipError_t e = hipGetDevice(&cl->device);
+    g_alloc_calls++;
     if(e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&cl->dev), bytes ? bytes : 16);
     if(e == hipSuccess) {
         pack_tables(plan, lb, host.data(), cl->dev, &cl->a);
@@ -1525,6 +1516,14 @@ int lvgpu_checksum(const void * in, int elem_bytes, uint64_t first, size_t n, ui
                        reinterpret_cast<unsigned long long *>(sum));
     HIP_TRY(hipGetLastError());
     return LVGPU_OK;
+}
+
+void lvgpu_debug_counters(lvgpu_debug_counters_t * out)
+{
+    if(out == nullptr) return;
+    out->alloc_calls = g_alloc_calls;
+    out->first_nonblack_launches = g_first_nb_launches;
+    out->band_pad_bytes = band_pad_of_last_launch();
 }
 
 int lvgpu_stream_create_cu_mask(void ** stream, const uint32_t * mask_words, int n_words)

@@ -43,9 +43,7 @@ struct BlendArgs {
     int raw_mode;          // dsc->blend_mode as given
     int has_mask;          // a per-pixel alpha exists (mask buffer or source alpha)
     int discard_dst;       // fused blend + flush only: the blended pixels go to out alone, dst is left as it is
-    int span_px;           // k_blend_rows: 0, or the caller owns the rows the area touches and every row is written in
-                           // whole aligned pieces of span_px pixels (a power of two >= 8), see k_blend_rows
-    int row_x0;            // with span_px: pixels between the start of the buffer row and the area's first pixel
+    int no_aa;             // anti-aliasing off: mask values (and source alpha) are rounded to 0 / 255 as they are loaded
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its L2).  Remap the block id
@@ -159,6 +157,26 @@ __device__ __forceinline__ void load_src(const void * base, long long px, uint32
     }
 }
 
+// Anti-aliasing off (lv_draw_sw_blend.c:150-156) applied to the words of one 8-pixel group as they sit in registers:
+// the mask bytes, and for the formats with their own alpha -- whose alpha plane is the mask of the blend
+// (lv_draw_sw_img.c:133-136) -- the alpha byte of every pixel.  The reference rounds the caller's mask buffer in place;
+// rounding on the way in gives the same pixels and leaves the buffer alone (rounding is idempotent).
+template <int SRC>
+__device__ __forceinline__ void no_aa_words(uint32_t * sw, uint2 & mk)
+{
+    mk.x = px_mask_no_aa_x4(mk.x);
+    mk.y = px_mask_no_aa_x4(mk.y);
+    if(SRC == SRC_ARGB8888 || SRC == SRC_RGBA8888) {
+#pragma unroll
+        for(int j = 0; j < 8; j++) sw[j] = (sw[j] & 0x00FFFFFFu) | (px_mask_no_aa_x4(sw[j]) & 0xFF000000u);
+    }
+    else if(SRC == SRC_ARGB8565) {  // alpha = byte 3j + 2 of the group's 24 bytes
+        constexpr uint32_t AM[6] = {0x00FF0000u, 0x0000FF00u, 0xFF0000FFu, 0x00FF0000u, 0x0000FF00u, 0xFF0000FFu};
+#pragma unroll
+        for(int i = 0; i < 6; i++) sw[i] = (sw[i] & ~AM[i]) | (px_mask_no_aa_x4(sw[i]) & AM[i]);
+    }
+}
+
 // lv_color_mix over one 8-pixel group for the modes that are nothing but a mix (normal blend function, opacity from
 // opa and/or the mask), with the byte order folded into the data movement: one byte permute takes a stored pixel
 // out of its dword, exchanges its bytes if the build swaps them and spreads it over both halves
@@ -217,9 +235,10 @@ __device__ __forceinline__ uint4 blend_group_premult(const A & a, uint4 d, uint3
 
 // Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
 template <int SRC, int OM, bool BLENDED, class A>
-__device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
+__device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
     if(OM == OM_OPAQUE && SRC == SRC_RGB565) return make_uint4(sw[0], sw[1], sw[2], sw[3]);  // same stored format
+    if(OM != OM_OPAQUE && OM != OM_FILL_PREMULT && OM != OM_CONST && a.no_aa) no_aa_words<SRC>(sw, mk);
     if(OM == OM_FILL_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     if(!BLENDED && (OM == OM_CONST || OM == OM_MASK || OM == OM_FILL_MASK_OPA || OM == OM_MAP_MASK_OPA))
         return blend_group_mix<SRC, OM>(a, d, sw, mk);
@@ -242,7 +261,7 @@ __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, const uint3
     return make_uint4(rw[0], rw[1], rw[2], rw[3]);
 }
 template <int SRC, class A>
-__device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
+__device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
     return blend_group_s<SRC, OM_RUNTIME, true>(a, d, sw, mk, scan0, fnb);
 }
@@ -279,9 +298,10 @@ __host__ __device__ __forceinline__ bool fast_is_mix(int fast)
     return fast == FAST_MIX || fast == FAST_MIX_CONST || fast == FAST_MIX_FILL_OPA || fast == FAST_MIX_MAP_OPA;
 }
 template <int SRC, class A>
-__device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, const uint32_t * sw, uint2 mk, uint32_t scan0,
+__device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0,
                                                uint32_t fnb)
 {
+    if(a.no_aa) no_aa_words<SRC>(sw, mk);  // uniform over the launch
     if(fast == FAST_MIX) return blend_group_mix<SRC, OM_MASK>(a, d, sw, mk);
     if(fast == FAST_MIX_CONST) return blend_group_mix<SRC, OM_CONST>(a, d, sw, mk);
     if(fast == FAST_MIX_FILL_OPA) return blend_group_mix<SRC, OM_FILL_MASK_OPA>(a, d, sw, mk);
@@ -763,8 +783,6 @@ struct RowsMap {
     uint32_t groups_per_row;  // lanes per row of the area: the 16-byte groups a row overlaps (worst case when rows differ)
     long long src_span;       // source pixels from the area's first to its last pixel, + 1: what a wide source load may touch
     long long mask_span;      // the same for the mask, in bytes
-    uint32_t blocks_per_frame, frames_in_grid;  // the 1-D grid: blocks_per_frame * frames_in_grid blocks
-    int remap;                // deal the blocks to the XCDs frame by frame (xcd_remap)
 };
 
 // Store the pixels of r whose bit is set in pm (bit j = pixel j of the 16-byte group at p), nothing else: 8-, 4- and
@@ -798,65 +816,36 @@ __device__ __forceinline__ void store_group_masked(uint16_t * p, uint4 r, uint32
 // and mask loads, the vector blend, and a store of the area's pixels only.  A wide source or mask load that would
 // leave the rows that belong to the area (first group of the first row, last group of the last row) is replaced by
 // loads of the area's pixels alone.
-// With a.span_px set (the caller owns the buffer rows the area touches: nobody else writes them while the call runs)
-// every row is written in whole aligned pieces of span_px pixels instead: the lanes also take the groups that complete
-// the first and the last piece of a row, inside the buffer row, load them and store them back as they are.  A partly
-// written 64-byte piece costs the memory system a read-modify-write; a whole one is a plain write (201x101 area in
-// 480-pixel-wide buffers: 47 -> 6x % of the HBM peak for 8 % more bytes asked for).
 constexpr int ROWS_UNROLL = 1;  // groups per lane (all loaded before any is blended); 2 measured 2-5 % slower
 template <int SRC, int OM>
 __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, RowsMap map)
 {
     const uint32_t n_groups = map.groups_per_row * (uint32_t)a.h;
-    // The grid is blocks_per_frame x frames_in_grid blocks, block after block of a frame.  With map.remap the blocks of
-    // one XCD take a contiguous eighth of them, i.e. whole frames: the lines that two neighbouring blocks of a frame
-    // share (a row split between them) then meet in one L2 instead of being fetched and written back partly by two.
-    const uint32_t blk = map.remap ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const uint32_t f0 = blk / map.blocks_per_frame, c = blk - f0 * map.blocks_per_frame;
-    const uint32_t idx0 = c * (256 * ROWS_UNROLL) + threadIdx.x;
+    const uint32_t idx0 = blockIdx.x * (256 * ROWS_UNROLL) + threadIdx.x;
     if(idx0 >= n_groups) return;
-    for(uint32_t f = f0; f < (uint32_t)a.n_frames; f += map.frames_in_grid) {
+    for(uint32_t f = blockIdx.y; f < (uint32_t)a.n_frames; f += gridDim.y) {
         const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
         uint16_t * grp[ROWS_UNROLL];
-        uint32_t pm[ROWS_UNROLL], ps[ROWS_UNROLL], scan0[ROWS_UNROLL];  // pixels of the group to blend / to store
+        uint32_t pm[ROWS_UNROLL], scan0[ROWS_UNROLL];
         uint4 d[ROWS_UNROLL];
         uint32_t sw[ROWS_UNROLL][SrcWords<SRC>::N];
         uint2 mk[ROWS_UNROLL];
 #pragma unroll
         for(int u = 0; u < ROWS_UNROLL; u++) {
             const uint32_t idx = idx0 + (uint32_t)u * 256u;
-            pm[u] = ps[u] = 0;
+            pm[u] = 0;
             mk[u] = make_uint2(0, 0);
             if(idx >= n_groups) continue;
             const uint32_t y = idx / map.groups_per_row, k = idx - y * map.groups_per_row;
             uint16_t * row = a.dst + (long long)f * a.dst_fs + (size_t)y * a.dst_stride;
-            const uint32_t A = (uint32_t)(reinterpret_cast<uintptr_t>(row) >> 1);  // pixel address of the row's first pixel, low bits
-            int x_lo, j0, j1, s0, s1;
-            if(a.span_px == 0) {
-                const int off = (int)(A & 7u);  // row start within its 16-byte group
-                x_lo = (int)k * 8 - off;
-                if(x_lo >= a.w) continue;
-                j0 = s0 = x_lo < 0 ? -x_lo : 0;
-                j1 = s1 = a.w - x_lo < 8 ? a.w - x_lo : 8;  // pixels [j0, j1) are the area's
-            }
-            else {
-                const uint32_t sm = (uint32_t)a.span_px - 1u;
-                int lo = -(int)(A & sm), hi = a.w + (int)((0u - (A + (uint32_t)a.w)) & sm);  // whole pieces around the row, relative to its first pixel
-                lo = max(lo, -a.row_x0);                                                      // ... inside the buffer row
-                hi = min(hi, a.dst_stride - a.row_x0);
-                x_lo = lo - (int)((A + (uint32_t)lo) & 7u) + (int)k * 8;
-                if(x_lo >= hi) continue;
-                j0 = min(8, x_lo < 0 ? -x_lo : 0);
-                j1 = max(j0, a.w - x_lo < 8 ? a.w - x_lo : 8);
-                s0 = x_lo < lo ? lo - x_lo : 0;
-                s1 = hi - x_lo < 8 ? hi - x_lo : 8;
-            }
+            const int off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7u);  // row start within its 16-byte group
+            const int x_lo = (int)k * 8 - off;
+            if(x_lo >= a.w) continue;
+            const int j0 = x_lo < 0 ? -x_lo : 0, j1 = a.w - x_lo < 8 ? a.w - x_lo : 8;  // pixels [j0, j1) are the area's
             pm[u] = ((1u << j1) - 1u) & ~((1u << j0) - 1u);
-            ps[u] = ((1u << s1) - 1u) & ~((1u << s0) - 1u);
             grp[u] = row + x_lo;
             scan0[u] = y * (uint32_t)a.w + (uint32_t)x_lo;
             d[u] = *reinterpret_cast<const uint4 *>(grp[u]);
-            if(pm[u] == 0) continue;  // a group beside the area: stored back as it is
             if(SRC != SRC_FILL) {
                 const long long so = (long long)y * a.src_stride + x_lo;
                 if(so >= 0 && so + 8 <= map.src_span) load_src_unaligned<SRC>(a.src, (long long)f * a.src_fs + so, sw[u]);
@@ -882,20 +871,10 @@ __global__ __launch_bounds__(256) void k_blend_rows(BlendArgs a, RowsMap map)
         }
 #pragma unroll
         for(int u = 0; u < ROWS_UNROLL; u++) {
-            if(ps[u] == 0) continue;
-            uint4 r = d[u];
-            if(pm[u] != 0) {
-                r = blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d[u], sw[u], mk[u], scan0[u], fnb);
-                if(pm[u] != ps[u]) {  // pixels that are stored but not the area's keep what they held
-                    auto keep = [&](uint32_t blended, uint32_t held, int i) {
-                        const uint32_t m = (((pm[u] >> (2 * i)) & 1u) ? 0x0000FFFFu : 0u) | (((pm[u] >> (2 * i + 1)) & 1u) ? 0xFFFF0000u : 0u);
-                        return (blended & m) | (held & ~m);
-                    };
-                    r = make_uint4(keep(r.x, d[u].x, 0), keep(r.y, d[u].y, 1), keep(r.z, d[u].z, 2), keep(r.w, d[u].w, 3));
-                }
-            }
-            if(ps[u] == 0xFFu) *reinterpret_cast<uint4 *>(grp[u]) = r;
-            else store_group_masked(grp[u], r, ps[u]);
+            if(pm[u] == 0) continue;
+            const uint4 r = blend_group_s<SRC, OM, OM == OM_RUNTIME>(a, d[u], sw[u], mk[u], scan0[u], fnb);
+            if(pm[u] == 0xFFu) *reinterpret_cast<uint4 *>(grp[u]) = r;
+            else store_group_masked(grp[u], r, pm[u]);
         }
     }
 }
@@ -1190,6 +1169,7 @@ __global__ __launch_bounds__(256) void k_blend_argb_dst(BlendArgs a)
             const size_t mi = (fill && (uint32_t)a.raw_opa >= 253u) ? (size_t)y * a.w + x : (size_t)y * a.mask_stride + x;
             m = a.mask[(long long)f * a.mask_fs + mi];
         }
+        if(a.no_aa) m = px_mask_no_aa(m);
         uint32_t bg = dp[0] | (dp[1] << 8);
         if(a.swap) bg = px_swap16(bg);
         const ArgbOut r = argb_dst_px(a, fill, fg, m, bg, dp[2]);
@@ -1277,9 +1257,10 @@ __device__ __forceinline__ void argb_group_normal(const A & a, uint32_t * dw, co
 }
 
 template <int SRC, class A>
-__device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, const uint32_t * sw, uint2 mk, uint32_t color)
+__device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, uint32_t * sw, uint2 mk, uint32_t color)
 {
     constexpr bool fill = SRC == SRC_FILL;
+    if(a.no_aa) no_aa_words<SRC>(sw, mk);
     switch(argb_mode(a, fill)) {  // the same for every pixel of a launch / list item
         case AM_CONST: argb_group_normal<SRC, AM_CONST>(a, dw, sw, mk, color); return;
         case AM_MASK: argb_group_normal<SRC, AM_MASK>(a, dw, sw, mk, color); return;

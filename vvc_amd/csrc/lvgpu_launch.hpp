@@ -24,6 +24,7 @@ int tile_rows_per_phase(const char * env_name, int chosen);
 int launch_tile(int fmt, const BlendArgs & a, hipStream_t st);
 int launch_tile_col(int fmt, const BlendArgs & a, hipStream_t st);
 int launch_band(int fmt, const BlendArgs & a, hipStream_t st);   // fmt: SRC_FILL or SRC_RGB565
+uint32_t band_pad_of_last_launch();  // dynamic LDS the calling thread's last k_band launch asked for (diagnostics)
 int launch_tile_any(int fmt, const BlendArgs & a, hipStream_t st);
 int launch_rows(int fmt, const BlendArgs & a, hipStream_t st);
 

@@ -2,9 +2,10 @@
 //
 // Single-frame, host-buffer versions of the plug-in points of LVGL 8.x: lv_draw_sw_ctx_t.blend,
 // lv_draw_ctx_t.wait_for_finish, lv_disp_drv_t.draw_ctx_init/deinit/size and lv_disp_drv_t.flush_cb.
-// Immediate mode (default): each blend call stages the touched rectangle into device memory, runs the batch
-// kernels with n_frames = 1 and copies the result back before it returns.
-// Deferred mode (lvgpu_lvgl_set_deferred): blend calls only copy their source/mask rectangles into a queue; the
+// Immediate mode: each blend call stages the touched rectangle into device memory, runs the batch kernels with
+// n_frames = 1 and copies the result back before it returns.
+// Deferred mode (lvgpu_lvgl_set_deferred; the default for displays flushed by lvgpu_flush_cb): blend calls only copy
+// their source/mask rectangles into a queue; the
 // queue is submitted as ONE display list (draw buffer up, one launch, draw buffer down) when something is about
 // to look at the buffer -- lvgpu_flush_cb, lvgpu_wait_for_finish, the layer and buffer_copy hooks, a change of
 // draw_ctx->buf, context deinit.
@@ -30,7 +31,8 @@ init_ctx_fn g_sw_init_ctx = nullptr;
 blend_fn g_sw_blend_basic = nullptr;
 flush_ready_fn g_flush_ready = nullptr;
 int g_swap = 1;
-int g_deferred = 0;
+int g_deferred = -1;  // 1 on, 0 off, -1: on for displays flushed by lvgpu_flush_cb
+int g_inject_fail = 0;  // > 0: the n-th immediate blend from now fails before it touches the GPU (lvgpu_lvgl_inject_failure)
 std::atomic<uint64_t> g_blend_gpu{0}, g_blend_delegated{0}, g_flush_gpu{0}, g_errors{0}, g_lists{0}, g_replays{0}, g_submit_ns{0}, g_in_place{0};
 
 typedef void * (*layer_init_fn)(lvgpu_lv_draw_ctx_t *, void *, int);
@@ -47,7 +49,8 @@ struct QItem {
     uint64_t src_off, mask_off;
     uint16_t color;
     uint8_t opa, mode, has_src, has_mask;
-    uint8_t pad[2];
+    uint8_t flags;  // LVGPU_BLEND_FLAG_* of the item
+    uint8_t pad[1];
 };
 
 // Growable pinned host memory: the sources and masks of the queued blends are copied straight into it, so the one
@@ -80,9 +83,7 @@ struct Queue {
     // the usual case for a UI between two changes of its layout; the bytes of the masks and images may differ) is drawn
     // by replaying the list planned for the previous one.
     std::vector<QItem> prev_items;
-    const void * prev_fb = nullptr;     // where the previous submit's launch drew (device address) ...
-    const void * prev_arena = nullptr;  // ... and read its sources and masks from
-    void * prev_buf = nullptr;
+    const void * prev_arena = nullptr;  // where the previous submit's launch read its sources and masks (device address)
     lvgpu_area_t prev_area{0, 0, 0, 0};
     bool prev_transp = false;
     int prev_sig = -1;             // -1: nothing recorded; else 0 = no flush, 1 + rot * 2 + swap = fused flush
@@ -116,8 +117,9 @@ constexpr uint32_t MAGIC = 0x4C564750u;  // "LVGP"
 
 [[noreturn]] void die(const char * what, hipError_t e)
 {
-    // The callbacks return void and a silent CPU substitute would hide a broken installation.
-    fprintf(stderr, "lvgpu: %s failed: %s -- aborting (there is no CPU fallback)\n", what, hipGetErrorString(e));
+    // The callbacks return void; where the call cannot be handed to the host's own renderer any more (deferred mode,
+    // a result already on its way back) a failure must not go unnoticed.
+    fprintf(stderr, "lvgpu: %s failed: %s -- aborting\n", what, hipGetErrorString(e));
     g_errors++;
     abort();
 }
@@ -164,19 +166,6 @@ void drop_compiled(Queue * q)
     q->uncompilable = false;
     q->prev_sig = -1;
     q->prev_seen = 0;
-}
-
-void ensure_capacity(ShimCtx * s, size_t px)
-{
-    if(px <= s->cap_px) return;
-    if(s->d_dst) HIP_OR_DIE(hipFree(s->d_dst));
-    if(s->d_src) HIP_OR_DIE(hipFree(s->d_src));
-    if(s->d_mask) HIP_OR_DIE(hipFree(s->d_mask));
-    size_t cap = px < 65536 ? 65536 : px;
-    HIP_OR_DIE(hipMalloc(&s->d_dst, cap * 3));  // 3 bytes per pixel when the screen is transparent (ARGB8565)
-    HIP_OR_DIE(hipMalloc(&s->d_src, cap * 2));
-    HIP_OR_DIE(hipMalloc(&s->d_mask, cap));
-    s->cap_px = cap;
 }
 
 inline int aw(const lvgpu_lv_area_t * a) { return a->x2 - a->x1 + 1; }
@@ -249,7 +238,9 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
 
     // the same content as the previous submit?
     const int sig = fr ? 1 + fr->rot * 2 + (fr->swap_bytes ? 1 : 0) : 0;
-    const bool same = q->prev_sig == sig && q->prev_buf == q->buf && q->prev_fb == fb && q->prev_arena == arena && q->prev_transp == q->transp &&
+    // (the draw buffer is not part of the key: a display with two draw buffers alternates between them from refresh to
+    // refresh, and a compiled list is replayed over any buffer of the same geometry)
+    const bool same = q->prev_sig == sig && q->prev_arena == arena && q->prev_transp == q->transp &&
                       memcmp(&q->prev_area, &q->buf_area, sizeof(lvgpu_area_t)) == 0 && q->prev_items.size() == q->items.size() &&
                       memcmp(q->prev_items.data(), q->items.data(), q->items.size() * sizeof(QItem)) == 0;
     if(!same) {
@@ -257,8 +248,6 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         q->compiled = nullptr;
         q->uncompilable = false;
         q->prev_items = q->items;
-        q->prev_buf = q->buf;
-        q->prev_fb = fb;
         q->prev_arena = arena;
         q->prev_area = q->buf_area;
         q->prev_transp = q->transp;
@@ -292,6 +281,7 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
             b.blend_mode = it.mode;
             b.color_16_swap = (uint8_t)g_swap;
             b.dst_argb8565 = q->transp ? 1 : 0;
+            b.flags = it.flags;
         }
         if(same && !q->uncompilable) {  // second refresh in a row with this content: plan it once and keep the plan
             rc = lvgpu_list_create(&q->batch[0], q->batch.data(), (int32_t)q->batch.size(), fr ? 1 : 0, fr ? fr->rot : 0,
@@ -304,7 +294,7 @@ void submit(ShimCtx * s, const FlushReq * fr = nullptr)
         }
     }
     if(q->compiled) {
-        rc = lvgpu_list_replay(q->compiled, nullptr, 0, out, (int64_t)W * H, st);
+        rc = lvgpu_list_replay(q->compiled, fb, 0, out, (int64_t)W * H, st);
         drawn = rc == LVGPU_OK;
         if(drawn) g_replays++;
     }
@@ -383,7 +373,9 @@ void lvgpu_lvgl_bind(void * init_ctx, void * blend_basic, void * flush_ready_p)
 
 void lvgpu_lvgl_set_color_16_swap(int swap) { g_swap = swap ? 1 : 0; }
 
-void lvgpu_lvgl_set_deferred(int on) { g_deferred = on ? 1 : 0; }
+void lvgpu_lvgl_set_deferred(int on) { g_deferred = on > 0 ? 1 : (on < 0 ? -1 : 0); }
+
+void lvgpu_lvgl_inject_failure(int nth_blend) { g_inject_fail = nth_blend > 0 ? nth_blend : 0; }
 
 void * lvgpu_lvgl_buf_alloc(size_t bytes)
 {
@@ -423,7 +415,8 @@ void lvgpu_draw_ctx_init(lvgpu_lv_disp_drv_t * drv, lvgpu_lv_draw_ctx_t * draw_c
     // LVGL's own software rotation reads the draw buffer on the CPU between rendering and flush_cb
     // (libraries/lvgl/src/core/lv_refr.c:1262-1296) with no hook in between once wait_for_finish is cleared, so a
     // display that uses it keeps the immediate mode.
-    if(g_deferred && !drv->sw_rotate) {
+    const bool deferred = g_deferred > 0 || (g_deferred < 0 && drv->flush_cb == lvgpu_flush_cb);
+    if(deferred && !drv->sw_rotate) {
         Queue * q = new Queue();
         s->q = q;
         // lv_draw_sw_blend calls wait_for_finish before EVERY blend (lv_draw_sw_blend.c:103), which would submit
@@ -517,11 +510,17 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
         src += (size_t)src_stride * (a.y1 - dsc->blend_area->y1) + (a.x1 - dsc->blend_area->x1);
     }
     int mask_stride = 0;
+    // :150-156: with anti-aliasing off the mask is rounded to 0 / 255 -- in the caller's buffer, over the whole
+    // mask_area, as the reference does it: LVGL's producers read their masks again after the call (the shadow renderer
+    // blends straight out of its shadow buffer, lv_draw_sw_rect.c:572, and later takes opacities from the same bytes,
+    // :661), so the rounding is part of what a drop-in has to reproduce.  The batched ABI has the flag
+    // LVGPU_BLEND_FLAG_NO_AA for callers whose masks are theirs alone; here the bytes are rounded already.
+    if(mask && drv->antialiasing == 0) {
+        const int32_t n = aw(dsc->mask_area) * ah(dsc->mask_area);
+        for(int32_t i = 0; i < n; i++) mask[i] = mask[i] > 128 ? 255 : 0;
+    }
+    const uint8_t no_aa = 0;
     if(mask) {
-        if(drv->antialiasing == 0) {  // :150-156, in place over the whole mask as the reference does
-            const int32_t n = aw(dsc->mask_area) * ah(dsc->mask_area);
-            for(int32_t i = 0; i < n; i++) mask[i] = mask[i] > 128 ? 255 : 0;
-        }
         mask_stride = aw(dsc->mask_area);
         mask += (size_t)mask_stride * (a.y1 - dsc->mask_area->y1) + (a.x1 - dsc->mask_area->x1);
     }
@@ -545,6 +544,7 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
         it.color = dsc->color;
         it.opa = dsc->opa;
         it.mode = dsc->blend_mode;
+        it.flags = no_aa;
         if(src) {
             it.src_off = (q->arena.size + 15) & ~(size_t)15;
             uint8_t * base = q->arena.grow_to(it.src_off + px * 2);
@@ -568,47 +568,87 @@ void lvgpu_blend(lvgpu_lv_draw_ctx_t * draw_ctx, const lvgpu_lv_draw_sw_blend_ds
         g_blend_gpu++;
         return;
     }
-    ensure_capacity(s, px);
+    // Immediate mode.  Until the result starts to travel back the host buffer is untouched, so a failure up to that
+    // point (no memory for the staging buffers, a refused copy or launch) is counted and the call is handed to the host
+    // program's lv_draw_sw_blend_basic -- the convention of LVGL's GPU back-ends
+    // (libraries/lvgl/src/draw/stm32_dma2d/lv_gpu_stm32_dma2d.c:127-130).  Without a bound fallback, or once the copy
+    // back has been issued, a failure ends the program: a frame with a hole in it must not go unnoticed.
     hipStream_t st = s->stream;
+    const char * what = nullptr;
+    hipError_t e = hipSuccess;
+    int rc = LVGPU_OK;
+#define STEP(expr)                                                       \
+    do {                                                                 \
+        if(what == nullptr && (e = (expr)) != hipSuccess) what = #expr; \
+    } while(0)
+    if(g_inject_fail > 0 && --g_inject_fail == 0) {  // test hook: see lvgpu_lvgl_inject_failure
+        what = "injected failure";
+        e = hipErrorOutOfMemory;
+    }
+    if(what == nullptr && px > s->cap_px) {
+        if(s->d_dst) (void)hipFree(s->d_dst);
+        if(s->d_src) (void)hipFree(s->d_src);
+        if(s->d_mask) (void)hipFree(s->d_mask);
+        s->d_dst = s->d_src = s->d_mask = nullptr;
+        s->cap_px = 0;
+        const size_t cap = px < 65536 ? 65536 : px;
+        STEP(hipMalloc(&s->d_dst, cap * 3));  // 3 bytes per pixel when the screen is transparent (ARGB8565)
+        STEP(hipMalloc(&s->d_src, cap * 2));
+        STEP(hipMalloc(&s->d_mask, cap));
+        if(what == nullptr) s->cap_px = cap;
+    }
     const bool overwrite = mask == nullptr && dsc->opa >= 253 && dsc->blend_mode == 0 && !drv->screen_transp;
     if(!overwrite)  // every other case reads the destination
-        HIP_OR_DIE(hipMemcpy2DAsync(s->d_dst, (size_t)w * dbpp, dest, (size_t)dest_stride * dbpp, (size_t)w * dbpp, h,
-                                    hipMemcpyHostToDevice, st));
-    if(src)
-        HIP_OR_DIE(hipMemcpy2DAsync(s->d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h,
-                                    hipMemcpyHostToDevice, st));
+        STEP(hipMemcpy2DAsync(s->d_dst, (size_t)w * dbpp, dest, (size_t)dest_stride * dbpp, (size_t)w * dbpp, h, hipMemcpyHostToDevice, st));
+    if(src) STEP(hipMemcpy2DAsync(s->d_src, (size_t)w * 2, src, (size_t)src_stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, st));
     if(mask) {
         if(drv->screen_transp && src == nullptr && dsc->opa >= 253)
             // fill_argb's opaque masked loop walks the mask as ONE run of w*h bytes (lv_draw_sw_blend.c:494-505: the
             // pointer is never advanced by mask_stride - w), so that run is what has to be staged
-            HIP_OR_DIE(hipMemcpyAsync(s->d_mask, mask, px, hipMemcpyHostToDevice, st));
+            STEP(hipMemcpyAsync(s->d_mask, mask, px, hipMemcpyHostToDevice, st));
         else
-            HIP_OR_DIE(hipMemcpy2DAsync(s->d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, h, hipMemcpyHostToDevice, st));
+            STEP(hipMemcpy2DAsync(s->d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, h, hipMemcpyHostToDevice, st));
     }
-
-    lvgpu_blend_batch_t b;
-    memset(&b, 0, sizeof(b));
-    b.dst = s->d_dst;
-    b.dst_frame_stride = (int64_t)px;
-    b.buf_area = lvgpu_area_t{0, 0, (int16_t)(w - 1), (int16_t)(h - 1)};
-    b.clip_area = b.buf_area;
-    b.blend_area = b.buf_area;
-    b.mask_area = b.buf_area;
-    b.src = src ? s->d_src : nullptr;
-    b.src_format = src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
-    b.mask = mask ? reinterpret_cast<const uint8_t *>(s->d_mask) : nullptr;
-    b.mask_res = LVGPU_MASK_RES_CHANGED;
-    b.n_frames = 1;
-    b.color = dsc->color;
-    b.opa = dsc->opa;
-    b.blend_mode = dsc->blend_mode;
-    b.color_16_swap = (uint8_t)g_swap;
-    b.dst_argb8565 = drv->screen_transp ? 1 : 0;
-    int rc = lvgpu_blend_batch(&b, st);
-    if(rc != LVGPU_OK) {
-        fprintf(stderr, "lvgpu: lvgpu_blend_batch failed (%d): %s -- aborting\n", rc, lvgpu_last_error());
+    if(what == nullptr) {
+        lvgpu_blend_batch_t b;
+        memset(&b, 0, sizeof(b));
+        b.dst = s->d_dst;
+        b.dst_frame_stride = (int64_t)px;
+        b.buf_area = lvgpu_area_t{0, 0, (int16_t)(w - 1), (int16_t)(h - 1)};
+        b.clip_area = b.buf_area;
+        b.blend_area = b.buf_area;
+        b.mask_area = b.buf_area;
+        b.src = src ? s->d_src : nullptr;
+        b.src_format = src ? LVGPU_SRC_RGB565 : LVGPU_SRC_FILL;
+        b.mask = mask ? reinterpret_cast<const uint8_t *>(s->d_mask) : nullptr;
+        b.mask_res = LVGPU_MASK_RES_CHANGED;
+        b.n_frames = 1;
+        b.color = dsc->color;
+        b.opa = dsc->opa;
+        b.blend_mode = dsc->blend_mode;
+        b.color_16_swap = (uint8_t)g_swap;
+        b.dst_argb8565 = drv->screen_transp ? 1 : 0;
+        b.flags = no_aa;
+        rc = lvgpu_blend_batch(&b, st);
+        if(rc != LVGPU_OK) what = "lvgpu_blend_batch";
+    }
+#undef STEP
+    if(what != nullptr) {
         g_errors++;
-        abort();
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(st);  // uploads that did start read src / mask, which the caller reuses after this call
+        if(g_sw_blend_basic == nullptr) {
+            fprintf(stderr, "lvgpu: %s failed (%s) and lv_draw_sw_blend_basic is not bound -- aborting\n", what,
+                    rc != LVGPU_OK ? lvgpu_last_error() : hipGetErrorString(e));
+            abort();
+        }
+        static std::atomic<int> said{0};
+        if(said.fetch_add(1) < 5)
+            fprintf(stderr, "lvgpu: %s failed (%s); this blend is drawn by lv_draw_sw_blend_basic\n", what,
+                    rc != LVGPU_OK ? lvgpu_last_error() : hipGetErrorString(e));
+        g_blend_delegated++;
+        g_sw_blend_basic(draw_ctx, dsc);
+        return;
     }
     HIP_OR_DIE(hipMemcpy2DAsync(dest, (size_t)dest_stride * dbpp, s->d_dst, (size_t)w * dbpp, (size_t)w * dbpp, h,
                                 hipMemcpyDeviceToHost, st));

@@ -107,6 +107,16 @@ __device__ __forceinline__ uint32_t px_blend_fn(uint32_t fg, uint32_t bg, int sw
     return (r << 11) | (g << 5) | b;
 }
 
+// A display with anti-aliasing off (disp->driver->antialiasing == 0): lv_draw_sw_blend_basic rounds every mask value
+// to 0 or 255 before it blends, `mask[i] > 128 ? LV_OPA_COVER : LV_OPA_TRANSP` (lv_draw_sw_blend.c:150-156).
+__device__ __forceinline__ uint32_t px_mask_no_aa(uint32_t m) { return m > 128u ? 255u : 0u; }
+// ... four mask bytes at once: a byte is above 128 iff its top bit is set and any of its other seven is.
+__device__ __forceinline__ uint32_t px_mask_no_aa_x4(uint32_t w)
+{
+    const uint32_t above = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) & w & 0x80808080u;
+    return (above >> 7) * 255u;
+}
+
 // Effective opacity per pixel for the masked modes.
 template <int OM>
 __device__ __forceinline__ uint32_t px_opa(uint32_t m, uint32_t opa)

@@ -22,6 +22,8 @@ int tile_rows_per_phase(const char * name, int chosen)
 
 namespace {
 
+thread_local uint32_t g_band_pad_last = 0;  // what the last k_band launch of this thread asked for beyond its static LDS
+
 template <int SRC>
 struct LaunchTile {
     static int run(const BlendArgs & a, hipStream_t st)
@@ -43,6 +45,24 @@ struct LaunchTile {
         return LVGPU_OK;
     }
 };
+// The most LDS one workgroup may ask for on the current device (static + dynamic), looked up once per device.
+// LVGPU_MAX_LDS_PER_BLOCK in the environment (bytes; read at every call) stands in for it: a switch for tests that
+// the band kernel's residency pad is dropped where it does not fit.
+size_t max_lds_per_block()
+{
+    if(const char * e = getenv("LVGPU_MAX_LDS_PER_BLOCK")) return (size_t)atoll(e);
+    static thread_local int dev_cached = -1;
+    static thread_local size_t cached = 0;
+    int dev = -1, v = 0;
+    if(hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
+    if(dev != dev_cached) {
+        if(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+        cached = (size_t)v;
+        dev_cached = dev;
+    }
+    return cached;
+}
+
 template <int SRC>
 int launch_band_src(const BlendArgs & a, hipStream_t st)
 {
@@ -50,22 +70,21 @@ int launch_band_src(const BlendArgs & a, hipStream_t st)
     const uint32_t bands = (H + BAND_H - 1) / BAND_H;
     const uint64_t n_blocks = (uint64_t)bands * a.n_frames;
     if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
-    // one workgroup per CU (RGB565 + A8 image: 68.0 % of peak uncapped, 69.3 % capped); the callers send the plain-mix case only
-    const uint32_t pad = residency_pad(st, BAND_PAD_LDS);
+    // one workgroup per CU (RGB565 + A8 image: 68.0 % of peak uncapped, 69.3 % capped); the callers send the plain-mix
+    // case only.  The kernel uses 64 KB of static LDS: the pad is a tuning and is left out where the device (or a
+    // runtime that keeps workgroups to 64 KB) would refuse the sum -- the launch itself never depends on it.
+    constexpr size_t BAND_STATIC_LDS = (size_t)BAND_H * (BAND_MAX_W / 8) * sizeof(uint4);
+    uint32_t pad = residency_pad(st, BAND_PAD_LDS);
+    if(BAND_STATIC_LDS + pad > max_lds_per_block()) pad = 0;
+    g_band_pad_last = pad;
     hipLaunchKernelGGL(k_band<SRC>, dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
-    hipError_t e = hipGetLastError();
-    if(e != hipSuccess && pad != 0) {
-        // the padded request (64 KB used + the pad) is above what a runtime that keeps workgroups to 64 KB of LDS accepts:
-        // the cap is a tuning, the launch is not
-        hipLaunchKernelGGL(k_band<SRC>, dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), 0, st, a, W, H, bands);
-        e = hipGetLastError();
-    }
-    LVGPU_LAUNCH_TRY(e);
+    LVGPU_LAUNCH_TRY(hipGetLastError());
     return LVGPU_OK;
 }
 }  // namespace
 
 int launch_tile(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchTile>(fmt, a, st); }
+uint32_t band_pad_of_last_launch() { return g_band_pad_last; }
 int launch_band(int fmt, const BlendArgs & a, hipStream_t st)
 {
     switch(fmt) {

@@ -20,7 +20,7 @@ LV_BLEND_MODE_NORMAL, LV_BLEND_MODE_ADDITIVE, LV_BLEND_MODE_SUBTRACTIVE, LV_BLEN
 LV_DISP_ROT_NONE, LV_DISP_ROT_90, LV_DISP_ROT_180, LV_DISP_ROT_270 = 0, 1, 2, 3
 SRC_FILL, SRC_RGB565, SRC_ARGB8888, SRC_RGBA8888, SRC_ARGB8565 = 0, 1, 2, 3, 4
 SYNTH_U16, SYNTH_MASK_UI, SYNTH_MASK_UNI, SYNTH_ARGB_UI, SYNTH_ARGB_UNI = 0, 1, 2, 3, 4
-FLAG_NO_AA, FLAG_OWNS_ROWS, FLAG_DISCARD_DST = 0x01, 0x02, 0x04   # LVGPU_BLEND_FLAG_*
+FLAG_NO_AA, FLAG_DISCARD_DST = 0x01, 0x04   # LVGPU_BLEND_FLAG_*
 
 _SRC_ELEM_BYTES = {SRC_RGB565: 2, SRC_ARGB8888: 4, SRC_RGBA8888: 4, SRC_ARGB8565: 3}
 
