@@ -2,8 +2,8 @@
 // scenes through lvgpu_blend / lvgpu_flush_cb, immediate and deferred, with the HOST code of the library built under
 // AddressSanitizer (queue arena, staging, hooks, chunk emission).  Needs a GPU; kernels are not instrumented.
 //   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Xarch_host -fsanitize=address -shared \
-//         -o build/asan/liblvgpu_asan.so vvc_amd/csrc/lvgpu.hip vvc_amd/csrc/lvgpu_tiles.hip \
-//         vvc_amd/csrc/lvgpu_rows.hip -x hip vvc_amd/csrc/lvgpu_lvgl_shim.cpp -ldl
+//         -o build/asan/liblvgpu_asan.so vvc_amd/csrc/lvgpu.hip vvc_amd/csrc/lvgpu_tiles.hip vvc_amd/csrc/lvgpu_tiles_col.hip \
+//         vvc_amd/csrc/lvgpu_tiles_any.hip vvc_amd/csrc/lvgpu_rows.hip -x hip vvc_amd/csrc/lvgpu_lvgl_shim.cpp -ldl
 //   clang++ -O1 -g -fsanitize=address -Iinclude tools/host_asan_dropin.cpp -o build/asan/dropin_check \
 //         build/asan/liblvgpu_asan.so oracle/_ref/liblvgl_swap1.so -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../oracle/_ref'
 //   ASAN_OPTIONS=detect_leaks=0 build/asan/dropin_check

@@ -24,7 +24,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 # dominant kernel of each workload (a substring of the demangled name in rocprofv3's tables)
-KERNEL = {"blend_flush": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile", "blend_flush_rgb565a8": "k_band",
+KERNEL = {"blend_flush": "k_tile", "blend_flush_nowb": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile", "blend_flush_rgb565a8": "k_band",
           "blend_rgb565a8": "k_blend_linear", "blend_flush_4k": "k_tile_col", "clipped_small": "k_blend_rows",
           "clipped_large": "k_blend_rows", "fill_translucent": "k_blend_linear", "fill_opaque": "k_blend_linear",
           "map_opaque": "k_blend_linear", "fill_masked": "k_blend_linear", "fill_masked_argb": "k_blend_argb_linear",
