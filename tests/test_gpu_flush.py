@@ -308,7 +308,8 @@ def test_discard_dst_is_for_the_fused_call_only(gpu):
 @pytest.mark.parametrize("rot", [1, 3, 2])
 @pytest.mark.parametrize("shape,fmt", [((64, 64), 2), ((128, 64), 1), ((100, 37), 4), ((480, 328), 2), ((72, 40), 0)])
 def test_blend_flush_without_antialiasing(gpu, oracle, rot, shape, fmt):
-    """LVGPU_BLEND_FLAG_NO_AA through the fused blend + flush kernels (tile, band, column, any-size, linear)."""
+    """LVGPU_BLEND_FLAG_NO_AA through lvgpu_blend_flush_batch: one pass for 0 / 180 degrees (the contiguous kernel rounds
+    the masks), blend + flush as two passes for the quarter turns (their kernels are compiled without the switch)."""
     W, H = shape
     N = 2
     rng = np.random.default_rng(W + H + rot + fmt)
@@ -339,7 +340,7 @@ def test_blend_flush_without_antialiasing(gpu, oracle, rot, shape, fmt):
                            mask_buf=None if mask is None else to_dev(mask), opa=255, src_format=fmt if fmt else None,
                            flags=gpu.FLAG_NO_AA)
         out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
-        assert "fused" in gpu.last_kernel() or (rot == 2 and (W * H) % 8)   # a half turn off the 8-pixel grid: two passes
+        assert ("fused" in gpu.last_kernel()) == (rot == 2 and (W * H) % 8 == 0)
         assert np.array_equal(to_np(d, np.uint16), exp), (swap, gpu.last_kernel())
         got = to_np(out, np.uint16).reshape(N, -1)
         for f in range(N):

@@ -173,9 +173,9 @@ int main(int argc, char ** argv)
         a.rot = 1;
         const uint32_t tiles_x = (W + 63) / 64, tiles_y = (H + 63) / 64, tpf = tiles_x * tiles_y;
         const uint32_t n_tiles = tpf * n_frames;
-        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_ARGB8888>, dim3((n_tiles + TILE_WPB - 1) / TILE_WPB), dim3(64 * TILE_WPB), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
+        ms = T.run([&] { hipLaunchKernelGGL((k_tile<SRC_ARGB8888, 8, false>), dim3((n_tiles + TILE_WPB - 1) / TILE_WPB), dim3(64 * TILE_WPB), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
         report("k_tile<ARGB8888> fused rot90 (10 B/px)", px * 10.0, ms);
-        ms = T.run([&] { hipLaunchKernelGGL(k_tile<SRC_COPY>, dim3((n_tiles + TILE_WPB - 1) / TILE_WPB), dim3(64 * TILE_WPB), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
+        ms = T.run([&] { hipLaunchKernelGGL((k_tile<SRC_COPY, 8, false>), dim3((n_tiles + TILE_WPB - 1) / TILE_WPB), dim3(64 * TILE_WPB), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
         report("k_tile<COPY> rot90 (4 B/px)", px * 4.0, ms);
     }
     {   // the column kernel on this frame size.  480x320, rebuilt with COL_WPB = 5 (a workgroup then writes 64 whole,
@@ -188,10 +188,10 @@ int main(int argc, char ** argv)
         for(uint32_t pad = 0; pad <= 64 * 1024; pad += 16 * 1024) {
             const uint32_t lds = pad > 64u * 8 * COL_WPB * 16 ? pad - 64u * 8 * COL_WPB * 16 : 0;
             snprintf(name, sizeof name, "k_tile_col<ARGB8888> WPB %d fused (10 B/px), +%u KB LDS", COL_WPB, lds / 1024);
-            float ms = T.run([&] { hipLaunchKernelGGL(k_tile_col<SRC_ARGB8888>, dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
+            float ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_ARGB8888, 8, false>), dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
             report(name, px * 10.0, ms);
             snprintf(name, sizeof name, "k_tile_col<COPY> WPB %d rot90 (4 B/px), +%u KB LDS", COL_WPB, lds / 1024);
-            ms = T.run([&] { hipLaunchKernelGGL(k_tile_col<SRC_COPY>, dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
+            ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_COPY, 4, false>), dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
             report(name, px * 4.0, ms);
         }
     }

@@ -496,6 +496,11 @@ bool needs_scan_order(const BlendArgs & a)
     return pm_black != a.pf.first_res;
 }
 
+// Items the tile pass does not take: a translucent fill that needs its scan-order pre-pass, and blends with
+// anti-aliasing off (the tile kernels are compiled without that switch; LVGL's own callback never sets it, it rounds
+// the caller's masks itself).  They run through the single-descriptor path in their place in the order.
+bool needs_own_pass(const BlendArgs & a) { return needs_scan_order(a) || a.no_aa != 0; }
+
 struct ListBuilder {
     int W, H;
     uint32_t tiles_x, tiles_y;
@@ -529,7 +534,6 @@ struct ListBuilder {
         it.pf = a.pf;
         it.raw_mode = a.raw_mode;
         it.has_mask = a.has_mask;
-        it.no_aa = a.no_aa;
         if(argb) {
             it.opa = (uint32_t)a.raw_opa;
             // fill_argb's opaque masked loop reads row y of the area at mask[y*w + x] (lv_draw_sw_blend.c:494-505)
@@ -914,7 +918,7 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
                 plan->items_noop++;
                 continue;
             }
-            if(tiles_ok && !needs_scan_order(ra[i])) {
+            if(tiles_ok && !needs_own_pass(ra[i])) {
                 lb.add(ra[i], items[i].src_format, areas[i], geom->buf_area);
                 continue;
             }
@@ -934,7 +938,7 @@ int run_list(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_t * items
     }
     for(int i = 0; i < n_items; i++) {
         if(res[i] != R_WORK) continue;
-        if(tiles_ok && !needs_scan_order(ra[i])) {
+        if(tiles_ok && !needs_own_pass(ra[i])) {
             lb.add(ra[i], items[i].src_format, areas[i], geom->buf_area);
             continue;
         }
@@ -1101,10 +1105,11 @@ int lvgpu_blend_flush_batch(const lvgpu_blend_flush_batch_t * d, void * stream)
         a.out_fs = d->out_frame_stride;
         a.rot = d->rotation;
         a.swap_out = d->swap_bytes ? 1 : 0;
-        const bool ok = out_ok && (transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format));
+        // (anti-aliasing off and a quarter turn: two passes -- the quarter-turn kernels are compiled without that switch)
+        const bool ok = out_ok && !(transposing && a.no_aa) && (transposing ? tile_ok(a, b.src_format) : linear_ok(a, b.src_format));
         // a quarter turn of a frame off the 8-pixel grid, or of misaligned buffers: still one pass (k_tile_any); the
         // blend must cover the whole buffer row by row (dst_stride == W holds, source and mask keep their own strides)
-        const bool any = transposing && !ok;
+        const bool any = transposing && !ok && !a.no_aa;
         if(ok || any) {
             a.discard_dst = (b.flags & LVGPU_BLEND_FLAG_DISCARD_DST) ? 1 : 0;
             uint32_t * owned = nullptr;
@@ -1208,6 +1213,9 @@ int lvgpu_list_create(const lvgpu_blend_batch_t * geom, const lvgpu_blend_batch_
         if(needs_scan_order(ra))
             return fail(LVGPU_ERR_UNSUPPORTED, "item %d needs a pass over its whole area first (translucent fill whose result "
                         "on black depends on scan order); use lvgpu_blend_list_batch", i);
+        if(ra.no_aa)
+            return fail(LVGPU_ERR_UNSUPPORTED, "item %d has LVGPU_BLEND_FLAG_NO_AA, which the tile pass does not take; use "
+                        "lvgpu_blend_list_batch", i);
         lb.add(ra, d.src_format, area, geom->buf_area);
     }
     ListPlan plan;

@@ -234,11 +234,13 @@ __device__ __forceinline__ uint4 blend_group_premult(const A & a, uint4 d, uint3
 }
 
 // Blend one 8-pixel group.  d: stored destination pixels; mk: 8 mask bytes (ignored for formats with own alpha).
-template <int SRC, int OM, bool BLENDED, class A>
+template <int SRC, int OM, bool BLENDED, bool NO_AA_SWITCH = true, class A>
 __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
     if(OM == OM_OPAQUE && SRC == SRC_RGB565) return make_uint4(sw[0], sw[1], sw[2], sw[3]);  // same stored format
-    if(OM != OM_OPAQUE && OM != OM_FILL_PREMULT && OM != OM_CONST && a.no_aa) no_aa_words<SRC>(sw, mk);
+    if constexpr(NO_AA_SWITCH && OM != OM_OPAQUE && OM != OM_FILL_PREMULT && OM != OM_CONST) {
+        if(a.no_aa) no_aa_words<SRC>(sw, mk);
+    }
     if(OM == OM_FILL_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     if(!BLENDED && (OM == OM_CONST || OM == OM_MASK || OM == OM_FILL_MASK_OPA || OM == OM_MAP_MASK_OPA))
         return blend_group_mix<SRC, OM>(a, d, sw, mk);
@@ -263,7 +265,7 @@ __device__ __forceinline__ uint4 blend_group_s(const A & a, uint4 d, uint32_t * 
 template <int SRC, class A>
 __device__ __forceinline__ uint4 blend_group(const A & a, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0, uint32_t fnb)
 {
-    return blend_group_s<SRC, OM_RUNTIME, true>(a, d, sw, mk, scan0, fnb);
+    return blend_group_s<SRC, OM_RUNTIME, true, false>(a, d, sw, mk, scan0, fnb);  // the caller has dealt with a.no_aa
 }
 // The full-frame kernels decide per pixel, except for the two cases whose cost is all memory traffic; the choice is
 // uniform over the launch:
@@ -297,16 +299,21 @@ __host__ __device__ __forceinline__ bool fast_is_mix(int fast)
 {
     return fast == FAST_MIX || fast == FAST_MIX_CONST || fast == FAST_MIX_FILL_OPA || fast == FAST_MIX_MAP_OPA;
 }
-template <int SRC, class A>
+// NO_AA_SWITCH: the kernel honours a.no_aa (the contiguous blend kernel does; the quarter-turn kernels are compiled
+// without it -- the branch costs their ARGB8888 instantiations 5 to 34 registers -- and the launcher sends such calls
+// through blend + flush as two passes).
+template <int SRC, bool NO_AA_SWITCH, class A>
 __device__ __forceinline__ uint4 blend_group_u(const A & a, int fast, uint4 d, uint32_t * sw, uint2 mk, uint32_t scan0,
                                                uint32_t fnb)
 {
-    if(a.no_aa) no_aa_words<SRC>(sw, mk);  // uniform over the launch
+    if constexpr(NO_AA_SWITCH) {
+        if(a.no_aa) no_aa_words<SRC>(sw, mk);  // uniform over the launch
+    }
     if(fast == FAST_MIX) return blend_group_mix<SRC, OM_MASK>(a, d, sw, mk);
     if(fast == FAST_MIX_CONST) return blend_group_mix<SRC, OM_CONST>(a, d, sw, mk);
     if(fast == FAST_MIX_FILL_OPA) return blend_group_mix<SRC, OM_FILL_MASK_OPA>(a, d, sw, mk);
     if(fast == FAST_MIX_MAP_OPA) return blend_group_mix<SRC, OM_MAP_MASK_OPA>(a, d, sw, mk);
-    if(fast == FAST_OPAQUE) return blend_group_s<SRC, OM_OPAQUE, false>(a, d, sw, mk, scan0, fnb);
+    if(fast == FAST_OPAQUE) return blend_group_s<SRC, OM_OPAQUE, false, false>(a, d, sw, mk, scan0, fnb);
     if(fast == FAST_PREMULT) return blend_group_premult(a, d, scan0, fnb);
     return blend_group<SRC>(a, d, sw, mk, scan0, fnb);
 }
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256) void k_blend_linear(BlendArgs a, uint32_t gpf,
         if(g < gpf) {
             uint4 r = d[u];
             if(BLEND) {
-                r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], g * 8, fnb);
+                r = blend_group_u<SRC, true>(a, fast, d[u], sw[u], mk[u], g * 8, fnb);
                 if(a.discard_dst) {}
                 else if(fast == FAST_OPAQUE) store_write_once(dst + (size_t)g * 8, r);
                 else *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
@@ -451,7 +458,10 @@ constexpr int TILE = 64;
 constexpr int TILE_WPB = 2;
 
 // NR: rows of its 8x8 block a lane loads, blends and transposes at a time (8, 4 or 2; see put_transposed).
-template <int SRC, int NR>
+// DISCARD: the blended pixels are not stored to dst (BlendArgs::discard_dst); a template parameter because a run-time
+// test around the stores keeps the compiler from mixing them with the arithmetic (480x320 fused: 69.4 against
+// 70.0 % of the HBM peak, 80x160: 53.9 against 58.9 %).
+template <int SRC, int NR, bool DISCARD>
 __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t tiles_y, uint32_t tpf,
                                               uint32_t n_tiles)
 {
@@ -509,8 +519,8 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
                 r[i] = d[i];
                 if(BLEND) {
                     const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
-                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
-                    if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + p) = r[i];
+                    r[i] = blend_group_u<SRC, false>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    if constexpr(!DISCARD) *reinterpret_cast<uint4 *>(dst + p) = r[i];
                 }
                 if(a.swap_out) r[i] = swap_group(r[i]);
             }
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
 // instruction (64 lanes x 16 bytes): only the first and the last line of a run are partial.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int COL_WPB = 8;  // 5 to 7 (fewer empty tile slots on 4K, 1080p) and 16 measured slower: the run length counts
-template <int SRC, int NR>
+template <int SRC, int NR, bool DISCARD>
 __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, uint32_t n_blocks)
 {
     __shared__ uint4 lds[64 * 8 * COL_WPB];   // [panel row of the block 0..63][chunk of the run 0..8*COL_WPB-1], swizzled
@@ -595,8 +605,8 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
                 r[i] = d[i];
                 if(BLEND) {
                     const size_t p = (size_t)(y0 + ph * NR + i) * W + x0;
-                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
-                    if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + p) = r[i];
+                    r[i] = blend_group_u<SRC, false>(a, fast, d[i], sw[i], mk[i], (uint32_t)p, fnb);
+                    if constexpr(!DISCARD) *reinterpret_cast<uint4 *>(dst + p) = r[i];
                 }
                 if(a.swap_out) r[i] = swap_group(r[i]);
             }
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
 // band the same as eight.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BAND_H = 64, BAND_WAVES = 8, BAND_MAX_W = 512;
-template <int SRC>
+template <int SRC, bool DISCARD>
 __global__ __launch_bounds__(64 * BAND_WAVES) void k_band(BlendArgs a, int W, int H, uint32_t bands)
 {
     __shared__ uint4 lds[BAND_H * (BAND_MAX_W / 8)];   // [row of the band][chunk of the row ^ (row >> 3)], 64 chunks per row
@@ -684,8 +694,8 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void k_band(BlendArgs a, int W, in
         if(g < n_groups) {
             uint4 r = d[u];
             if(BLEND) {
-                r = blend_group_u<SRC>(a, fast, d[u], sw[u], mk[u], (uint32_t)band0 + g * 8, fnb);
-                if(!a.discard_dst) *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
+                r = blend_group_u<SRC, false>(a, fast, d[u], sw[u], mk[u], (uint32_t)band0 + g * 8, fnb);
+                if constexpr(!DISCARD) *reinterpret_cast<uint4 *>(dst + (size_t)g * 8) = r;
             }
             if(a.swap_out) r = swap_group(r);
             lds[row * (BAND_MAX_W / 8) + (cg ^ (row >> 3))] = r;
@@ -927,7 +937,7 @@ __device__ __forceinline__ void store_group_masked_any(uint16_t * p, uint4 r, ui
 // and writes complete panel rows, which follow each other in memory.  The exchange area is 8 KB of dynamic LDS per
 // wavefront: [panel row of the region 0..63][chunk of the run 0..8*wpb-1], swizzled.
 constexpr int ANY_WPB_MAX = 8;
-template <int SRC, int NR>
+template <int SRC, int NR, bool DISCARD>
 __global__ __launch_bounds__(64 * ANY_WPB_MAX) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
 {
     extern __shared__ uint4 lds[];
@@ -1014,8 +1024,8 @@ __global__ __launch_bounds__(64 * ANY_WPB_MAX) void k_tile_any(BlendArgs a, int 
                 r[i] = d[i];
                 if(BLEND && y < H) {
                     const size_t p = (size_t)y * a.dst_stride + x0;
-                    r[i] = blend_group_u<SRC>(a, fast, d[i], sw[i], mk[i], (uint32_t)(y * W + x0), fnb);
-                    if(!a.discard_dst) {
+                    r[i] = blend_group_u<SRC, false>(a, fast, d[i], sw[i], mk[i], (uint32_t)(y * W + x0), fnb);
+                    if constexpr(!DISCARD) {
                         if(full_x) store16_any(dst + p, r[i], false);
                         else store_group_masked_any(dst + p, r[i], pmx);
                     }
@@ -1256,11 +1266,13 @@ __device__ __forceinline__ void argb_group_normal(const A & a, uint32_t * dw, co
     argb_pack8(nv, dw);
 }
 
-template <int SRC, class A>
+template <int SRC, bool NO_AA_SWITCH = false, class A>
 __device__ __forceinline__ void argb_group(const A & a, uint32_t * dw, uint32_t * sw, uint2 mk, uint32_t color)
 {
     constexpr bool fill = SRC == SRC_FILL;
-    if(a.no_aa) no_aa_words<SRC>(sw, mk);
+    if constexpr(NO_AA_SWITCH) {
+        if(a.no_aa) no_aa_words<SRC>(sw, mk);
+    }
     switch(argb_mode(a, fill)) {  // the same for every pixel of a launch / list item
         case AM_CONST: argb_group_normal<SRC, AM_CONST>(a, dw, sw, mk, color); return;
         case AM_MASK: argb_group_normal<SRC, AM_MASK>(a, dw, sw, mk, color); return;
@@ -1350,8 +1362,8 @@ __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t
         }
     }
     if(g < gpf) {
-        argb_group<SRC>(a, dw[0], sw[0], mk[0], a.color);
-        argb_group<SRC>(a, dw[1], sw[1], mk[1], a.color);
+        argb_group<SRC, true>(a, dw[0], sw[0], mk[0], a.color);
+        argb_group<SRC, true>(a, dw[1], sw[1], mk[1], a.color);
     }
     xch[wave][3 * lane] = make_uint4(dw[0][0], dw[0][1], dw[0][2], dw[0][3]);
     xch[wave][3 * lane + 1] = make_uint4(dw[0][4], dw[0][5], dw[1][0], dw[1][1]);

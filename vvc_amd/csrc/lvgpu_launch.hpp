@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/lvgpu.h"
 #include "lvgpu_kernels.hpp"
 
@@ -44,6 +46,27 @@ int dispatch_src(int fmt, Args &&... args)
         case SRC_RGBA8888: return L<SRC_RGBA8888>::run(args...);
         case SRC_ARGB8565: return L<SRC_ARGB8565>::run(args...);
         default: return L<SRC_COPY>::run(args...);
+    }
+}
+
+// Calls f(rows-per-phase constant, discard constant) for the run-time pair (nr, discard): the quarter-turn kernels take
+// both as template parameters.  The rotation alone (SRC_COPY) stores nothing to dst, so it has the one variant.
+template <int SRC, class F>
+void with_nr_discard(int nr, bool discard, F && f)
+{
+    auto go = [&](auto nr_c) {
+        if constexpr(SRC != SRC_COPY) {
+            if(discard) {
+                f(nr_c, std::true_type{});
+                return;
+            }
+        }
+        f(nr_c, std::false_type{});
+    };
+    switch(nr) {
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
     }
 }
 

@@ -29,7 +29,6 @@ struct ListItem {
     PremultFill pf;        // OM_FILL_PREMULT only (lists hold such fills only when black needs no scan-order cache)
     int raw_mode;          // ARGB8565 destination: dsc->blend_mode as given (opa then holds dsc->opa as given)
     int has_mask;          // ARGB8565 destination: a per-pixel alpha exists (mask buffer or source alpha)
-    int no_aa;             // anti-aliasing off: mask values and source alpha are rounded to 0 / 255 (lv_draw_sw_blend.c:150-156)
 };
 
 struct ListArgs {
@@ -110,7 +109,6 @@ __device__ __forceinline__ void list_fetch(const ListItem & it, uint32_t f, int 
         m = p[2];
     }
     if(it.mask) m = it.mask[(long long)f * it.mask_fs + (long long)ay * it.mask_stride + ax];
-    if(it.no_aa) m = px_mask_no_aa(m);
 }
 
 // The same with the element positions given: si = source pixel index, mi = mask byte index (both include the frame).
@@ -133,7 +131,6 @@ __device__ __forceinline__ void list_fetch_at(const ListItem & it, int swap, lon
         m = p[2];
     }
     if(it.mask) m = it.mask[mi];
-    if(it.no_aa) m = px_mask_no_aa(m);
 }
 
 // The part of an item that falls into the wave's tile, in tile-relative pixels; (ox, oy) turns a tile-relative
@@ -222,7 +219,7 @@ __device__ __forceinline__ void list_groups(const ListItem & it, uint4 * tile4, 
         }
 #pragma unroll
         for(int u = 0; u < LG_UNROLL; u++) {
-            if(base + (uint32_t)LNT * u < n) tile4[li[u]] = blend_group_s<SRC, OM, BLENDED>(it, d[u], sw[u], mk[u], 0u, 0u);
+            if(base + (uint32_t)LNT * u < n) tile4[li[u]] = blend_group_s<SRC, OM, BLENDED, false>(it, d[u], sw[u], mk[u], 0u, 0u);
         }
     }
 }
@@ -273,7 +270,7 @@ __device__ __forceinline__ void list_dispatch(const ListItem & it, uint4 * tile4
 // What blend_group_s / px_core_s read, per lane (the lanes of a batch may work for different items).
 struct LaneView {
     uint32_t color, opa;
-    int opa_mode, blend_fn, swap, no_aa;
+    int opa_mode, blend_fn, swap;
     PremultFill pf;
 };
 
@@ -300,7 +297,6 @@ __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, ui
         v.opa_mode = it.opa_mode;
         v.blend_fn = it.blend_fn;
         v.swap = a.swap;
-        v.no_aa = it.no_aa;
         if(OM == OM_FILL_PREMULT || OM == OM_RUNTIME) v.pf = it.pf;
         if(idx < n_full) {  // the whole group lies inside the item: vector accesses
             uint32_t sw[SrcWords<SRC>::N];
@@ -311,7 +307,7 @@ __device__ __forceinline__ void list_batch(const ListArgs & a, uint4 * tile4, ui
                 mk = make_uint2(m.x, m.y);
             }
             const uint4 d = OM == OM_OPAQUE ? make_uint4(0, 0, 0, 0) : tile4[li];
-            tile4[li] = blend_group_s<SRC, OM, BLENDED>(v, d, sw, mk, 0u, 0u);
+            tile4[li] = blend_group_s<SRC, OM, BLENDED, false>(v, d, sw, mk, 0u, 0u);
         }
         else {  // only the pixels of pxmask belong to the item: nothing outside its rectangle is read
             const uint4 d = tile4[li];
@@ -486,7 +482,7 @@ __global__ __launch_bounds__(ListCfg<WPT>::BLOCK) void k_blend_list(ListArgs a)
 // Requires W % 16 == 0 so that tile rows start on 16-byte boundaries.
 // ---------------------------------------------------------------------------------------------------------------
 struct ArgbLaneView {
-    int raw_opa, raw_mode, has_mask, swap, no_aa;
+    int raw_opa, raw_mode, has_mask, swap;
 };
 
 template <int SRC>
@@ -503,7 +499,6 @@ __device__ __forceinline__ void argb_list_px(const ListItem & it, int swap, uint
     v.raw_mode = it.raw_mode;
     v.has_mask = it.has_mask;
     v.swap = swap;
-    v.no_aa = it.no_aa;  // list_fetch has rounded m already
     const ArgbOut r = argb_dst_px(v, SRC == SRC_FILL, fg, m, bg, dp[2]);
     if(r.wo) dp[2] = (uint8_t)r.opa;
     if(r.wc) {
@@ -533,7 +528,6 @@ __device__ __forceinline__ void argb_list_group(const ListItem & it, int swap, u
     v.raw_mode = it.raw_mode;
     v.has_mask = it.has_mask;
     v.swap = swap;
-    v.no_aa = it.no_aa;
     argb_group<SRC>(v, dw, sw, mk, it.color);
     p[0] = make_uint2(dw[0], dw[1]);
     p[1] = make_uint2(dw[2], dw[3]);

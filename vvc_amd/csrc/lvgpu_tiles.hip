@@ -36,11 +36,10 @@ struct LaunchTile {
         const uint32_t pad = SRC == SRC_COPY ? residency_pad(st, TILE_PAD_LDS_COPY)
                                              : (fast_is_mix(fast_path<SRC>(a)) ? residency_pad(st, TILE_PAD_LDS) : 0);
         const dim3 grid((uint32_t)((n_tiles + TILE_WPB - 1) / TILE_WPB)), block(64 * TILE_WPB);
-        switch(tile_rows_per_phase("LVGPU_TILE_NR", 8)) {
-            case 4: hipLaunchKernelGGL((k_tile<SRC, 4>), grid, block, pad, st, a, W, H, tiles_x, tiles_y, tpf, (uint32_t)n_tiles); break;
-            case 2: hipLaunchKernelGGL((k_tile<SRC, 2>), grid, block, pad, st, a, W, H, tiles_x, tiles_y, tpf, (uint32_t)n_tiles); break;
-            default: hipLaunchKernelGGL((k_tile<SRC, 8>), grid, block, pad, st, a, W, H, tiles_x, tiles_y, tpf, (uint32_t)n_tiles); break;
-        }
+        with_nr_discard<SRC>(tile_rows_per_phase("LVGPU_TILE_NR", 8), a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
+            hipLaunchKernelGGL((k_tile<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, pad, st, a, W, H,
+                               tiles_x, tiles_y, tpf, (uint32_t)n_tiles);
+        });
         LVGPU_LAUNCH_TRY(hipGetLastError());
         return LVGPU_OK;
     }
@@ -77,7 +76,8 @@ int launch_band_src(const BlendArgs & a, hipStream_t st)
     uint32_t pad = residency_pad(st, BAND_PAD_LDS);
     if(BAND_STATIC_LDS + pad > max_lds_per_block()) pad = 0;
     g_band_pad_last = pad;
-    hipLaunchKernelGGL(k_band<SRC>, dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
+    if(a.discard_dst) hipLaunchKernelGGL((k_band<SRC, true>), dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
+    else hipLaunchKernelGGL((k_band<SRC, false>), dim3((uint32_t)n_blocks), dim3(64 * BAND_WAVES), pad, st, a, W, H, bands);
     LVGPU_LAUNCH_TRY(hipGetLastError());
     return LVGPU_OK;
 }

@@ -20,18 +20,16 @@ struct LaunchTileAny {
         //   The rotation alone (46 registers at 8 rows per phase): one workgroup per column of 320 or 384 rows
         // (482x320: 67 % of the HBM peak with 5 wavefronts, 52 % with 4; 480x322: 64 % with 6, 50 % with 3), not above
         // six (466x466: 61 % with 4, 57 % with 8); frames above 400 rows gain from 2 rows per phase (466x466 60 -> 62 %,
-        // 1080p 64 -> 68 %), lower ones lose (135x240 66 -> 62 %), and with 2 rows per phase eight wavefronts on a column
-        // of eight tiles are ahead of two workgroups of four (464x464: 67 against 64 %).
+        // 1080p 64 -> 68 %), lower ones lose (135x240 66 -> 62 %).
         //   With the blend fused in, 8 rows per phase need 133 registers: three wavefronts per SIMD, and a workgroup
         // above four wavefronts has a CU to itself (240x135: 59 % with 3, 30 % with 5 to 8).  At 2 rows per phase (61
         // registers) the workgroup can be sized to the height like the rotation's: 466x466 52 -> 60 % (8 wavefronts),
-        // 481x321 49 -> 60 %, 480x322 53 -> 65 %, 482x320 58 -> 62 %, 390x390 50 -> 59 %.  Frames of up to three tiles
-        // of height keep 8 rows per phase (320x172 67 against 66 %, 240x135 level).
+        // 481x321 49 -> 60 %, 480x322 53 -> 65 %, 482x320 58 -> 62 %, 390x390 50 -> 59 %.  Frames of up to four tiles
+        // of height keep 8 rows per phase (320x172 67 against 66 %, 320x200 68 against 65 %, 240x135 and 240x240 level).
         const int tiles_y = (H + TILE - 1) / TILE;
-        const int nr = tile_rows_per_phase("LVGPU_ANY_NR", SRC == SRC_COPY ? (H > 400 ? 2 : 8) : (tiles_y <= 3 ? 8 : 2));
-        static const int order_copy[6] = {6, 5, 4, 3, 7, 8}, order_copy2[6] = {6, 5, 8, 7, 4, 3}, order_blend8[2] = {4, 3},
-                         order_blend[5] = {6, 8, 7, 5, 4};
-        const int * order = SRC == SRC_COPY ? (nr == 8 ? order_copy : order_copy2) : (nr == 8 ? order_blend8 : order_blend);
+        const int nr = tile_rows_per_phase("LVGPU_ANY_NR", SRC == SRC_COPY ? (H > 400 ? 2 : 8) : (tiles_y <= 4 ? 8 : 2));
+        static const int order_copy[6] = {6, 5, 4, 3, 7, 8}, order_blend8[2] = {4, 3}, order_blend[5] = {6, 8, 7, 5, 4};
+        const int * order = SRC == SRC_COPY ? order_copy : (nr == 8 ? order_blend8 : order_blend);
         const int n_order = SRC == SRC_COPY ? 6 : (nr == 8 ? 2 : 5);
         int wpb = tiles_y;
         if(wpb > 2) {
@@ -50,11 +48,10 @@ struct LaunchTileAny {
         if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
         const dim3 grid((uint32_t)n_blocks), block(64 * wpb);
         const size_t lds = (size_t)wpb * 8192;
-        switch(nr) {
-            case 4: hipLaunchKernelGGL((k_tile_any<SRC, 4>), grid, block, lds, st, a, W, H, tiles_x, cols_y, wpb); break;
-            case 2: hipLaunchKernelGGL((k_tile_any<SRC, 2>), grid, block, lds, st, a, W, H, tiles_x, cols_y, wpb); break;
-            default: hipLaunchKernelGGL((k_tile_any<SRC, 8>), grid, block, lds, st, a, W, H, tiles_x, cols_y, wpb); break;
-        }
+        with_nr_discard<SRC>(nr, a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
+            hipLaunchKernelGGL((k_tile_any<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, lds, st, a, W, H,
+                               tiles_x, cols_y, wpb);
+        });
         LVGPU_LAUNCH_TRY(hipGetLastError());
         return LVGPU_OK;
     }

@@ -23,11 +23,10 @@ struct LaunchTileCol {
         // from 61 to 66 %, 480x272 from 53 to 66 %, 1024x600 from 52 to 58 %, 1280x720 from 58 to 60 %.  The rotation
         // alone gains one to three points from 4 rows per phase at every height but 4K canvases, which like 2 (63 -> 65 %).
         const int nr_chosen = SRC == SRC_COPY ? (H > 1536 ? 2 : 4) : (H <= 768 ? 4 : 8);
-        switch(tile_rows_per_phase("LVGPU_COL_NR", nr_chosen)) {
-            case 4: hipLaunchKernelGGL((k_tile_col<SRC, 4>), grid, block, 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks); break;
-            case 2: hipLaunchKernelGGL((k_tile_col<SRC, 2>), grid, block, 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks); break;
-            default: hipLaunchKernelGGL((k_tile_col<SRC, 8>), grid, block, 0, st, a, W, H, tiles_x, cols_y, (uint32_t)n_blocks); break;
-        }
+        with_nr_discard<SRC>(tile_rows_per_phase("LVGPU_COL_NR", nr_chosen), a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
+            hipLaunchKernelGGL((k_tile_col<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, 0, st, a, W, H,
+                               tiles_x, cols_y, (uint32_t)n_blocks);
+        });
         LVGPU_LAUNCH_TRY(hipGetLastError());
         return LVGPU_OK;
     }
