@@ -157,8 +157,10 @@ typedef struct {
  *     caller that reads the bytes back as something else -- LVGL's shadow renderer takes opacities from a buffer it has
  *     blended out of, libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:572,661 -- has to round them itself, which is what
  *     lvgpu_blend of lvgpu_lvgl.h does instead of setting this flag).  Accepted by
- *     every entry point that takes a lvgpu_blend_batch_t; without a mask (or with mask_res FULL_COVER) it does nothing,
- *     as in the reference.
+ *     lvgpu_blend_batch, lvgpu_blend_batch_noalloc and lvgpu_blend_flush_batch (which then blends and flushes in two
+ *     launches when the rotation is a quarter turn: the fused quarter-turn kernels are compiled without the switch);
+ *     lvgpu_list_create answers LVGPU_ERR_UNSUPPORTED for an item that carries it.  Without a mask (or with mask_res
+ *     FULL_COVER) it does nothing, as in the reference.
  * LVGPU_BLEND_FLAG_DISCARD_DST  lvgpu_blend_flush_batch only (LVGPU_ERR_ARG anywhere else): the caller does not need the
  *     blended draw buffer after the flush, only the panel image.  That is the reference's own configuration: its port
  *     forces full_refresh (src/lv_port.c:241), so LVGL redraws the whole buffer on every refresh

@@ -1,6 +1,8 @@
 """Long-running fuzz of the single-descriptor entry points against the oracle (not collected by pytest): random
 buffer sizes and alignments, every source format, masks, opacities, blend modes, clip areas, both swap modes,
-lvgpu_blend_batch and lvgpu_blend_flush_batch.
+lvgpu_blend_batch and lvgpu_blend_flush_batch, the latter also without the write-back (LVGPU_BLEND_FLAG_DISCARD_DST);
+masked fills and maps also with anti-aliasing off (LVGPU_BLEND_FLAG_NO_AA; the oracle gets the mask already rounded,
+which is what the reference's in-place rounding amounts to for the destination).
     python tests/perf/fuzz_blend.py [seconds] [seed]"""
 import os
 import sys
@@ -48,7 +50,13 @@ def main():
         dst = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
         if rng.random() < 0.5:
             dst[:, : max(1, H // 2)] = 0
-        exp = _apply_oracle(O, dst, area, [it], swap, W)
+        flags = 0
+        it_o = it
+        if it["fmt"] in (0, 1) and rng.random() < 0.2:
+            flags |= gpu.FLAG_NO_AA
+            if it["mask"] is not None:
+                it_o = dict(it, mask=np.where(it["mask"] > 128, 255, 0).astype(np.uint8))
+        exp = _apply_oracle(O, dst, area, [it_o], swap, W)
         off = int(rng.choice([0, 0, 0, 1, 3, 4, 8]))  # element offset of the batch inside its allocation
         base = torch.zeros(N * H * W + 16, dtype=torch.int16, device="cuda")
         d = base[off:off + N * H * W].view(N, H, W)
@@ -60,6 +68,9 @@ def main():
                            blend_mode=it["mode"], src_format=it["fmt"])
         rot = int(rng.integers(0, 5))
         ok = True
+        if rot < 4 and rng.random() < 0.3:
+            flags |= gpu.FLAG_DISCARD_DST
+        dsc.flags = flags
         if rot < 4:
             sb = int(rng.integers(0, 2))
             out = gpu.blend_flush(ctx, dsc, rot, swap_bytes=sb)
@@ -68,12 +79,14 @@ def main():
         else:
             gpu.lv_draw_sw_blend(ctx, dsc)
         kernels[gpu.last_kernel()] = kernels.get(gpu.last_kernel(), 0) + 1
-        ok = ok and np.array_equal(to_np(d.contiguous(), np.uint16), exp) and int(base[:off].abs().sum()) == 0 \
+        # without the write-back the draw buffer keeps its pixels where blend and flush ran as one pass
+        kept = dst if (flags & gpu.FLAG_DISCARD_DST) and "(fused)" in gpu.last_kernel() else exp
+        ok = ok and np.array_equal(to_np(d.contiguous(), np.uint16), kept) and int(base[:off].abs().sum()) == 0 \
             and int(base[off + N * H * W:].abs().sum()) == 0
         n_cases += 1
         if not ok:
-            print("MISMATCH seed %d case %d: swap %d %dx%d N %d off %d rot %d item %s kernel %s" % (
-                seed, n_cases, swap, W, H, N, off, rot, {k: v for k, v in it.items() if k not in ("src", "mask")},
+            print("MISMATCH seed %d case %d: swap %d %dx%d N %d off %d rot %d flags %d item %s kernel %s" % (
+                seed, n_cases, swap, W, H, N, off, rot, flags, {k: v for k, v in it.items() if k not in ("src", "mask")},
                 gpu.last_kernel()), flush=True)
             sys.exit(1)
         if n_cases % 200 == 0:
