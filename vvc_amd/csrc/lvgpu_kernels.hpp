@@ -1229,13 +1229,57 @@ __device__ __forceinline__ void argb_pack8(const uint32_t * nv, uint32_t * dw)  
     dw[5] = (nv[6] >> 16) | (nv[7] << 8);
 }
 
-// set_px_argb (lv_draw_sw_blend.c:378-402) over the group for the normal blend mode, opacity per AM: no branches,
-// every pixel independent of its neighbours (the kernels that use this are bound by instruction issue).
+// set_px_argb (lv_draw_sw_blend.c:378-402) with lv_color_mix_with_alpha (lv_color.h:530-577) for one stored pixel, in
+// the fewest instructions this file knows (the ARGB8565 kernels are bound by instruction issue).
+//   v      the pixel as stored: colour in bytes 0-1 (exchanged when sel_* say so), alpha in byte 2, anything in byte 3
+//   fgs    the foreground colour, native, spread: (c | c << 16) & 0x07E0F81F
+//   o      the foreground's opacity, 0..255
+//   sel_dup / sel_out   v_perm selectors: stored colour -> native colour in both halves; {colour, alpha} -> stored
+// Returns the new pixel in bits 0-23, bits 24-31 zero.
+// The reference's four cases become one lv_color_mix whose 5-bit ratio and resulting alpha are selected:
+//   o >= 253 or alpha <= 2      foreground as it is (ratio 32 returns it exactly), alpha o           (:537-541)
+//   o <= 2                      background as it is (ratio 0), alpha kept                            (:543-547)
+//   alpha >= 253                ratio from o, alpha 255: the general case with the alpha taken as 255 (:549-552)
+//   else                        alpha' = 255 - ((255 - o)(255 - alpha) >> 8) = (65535 - (255 - o)(255 - alpha)) >> 8,
+//                               ratio = o * 255 / alpha'                                              (:554-575)
+// and set_px_argb's "colour only if the new alpha is above 2" (:391) is ratio 0 whenever o <= 2: the new alpha is at
+// most 2 only when both o and the old alpha are.
+// (o * 255 / alpha' + 4) >> 3, all divisions rounding down, equals floor(o * 31.875 / alpha' + 0.5).  In float: o * 31.875
+// is exact, the reciprocal's error moves the product by less than 1e-5, and a value that is not whole lies at least
+// 1 / (8 * 255) under the next one, so adding 0.5002 before truncating gives the integer result for every operand pair
+// (checked for all 256 x 256 pairs with the reciprocal off by up to two units in the last place, and on the GPU).
+__device__ __forceinline__ uint32_t argb_px_normal(uint32_t v, uint32_t fgs, uint32_t o, uint32_t sel_dup, uint32_t sel_out,
+                                                   bool skip = false)
+{
+    const uint32_t bgs = __builtin_amdgcn_perm(0u, v, sel_dup) & 0x07E0F81Fu;
+    const uint32_t b = __builtin_amdgcn_ubfe(v, 16, 8);
+    // 65535 - (255 - o)(255 - alpha) = (510 + 255 o) + (255 - o) alpha, alpha taken as 255 when it covers: two v_mad_u32_u24
+    const uint32_t t = __umul24(o ^ 255u, b > 252u ? 255u : b) + (__umul24(o, 255u) + 510u);   // 510 <= t <= 65535
+    const uint32_t opa4 = t >> 8;
+    uint32_t m5d = (uint32_t)__builtin_fmaf((float)o * 31.875f, __builtin_amdgcn_rcpf((float)((t >> 8) & 0xFFu)), 0.5002f);
+    // computed for every pixel: as an operand of the selects below the compiler would put the division under a branch
+    // per pixel, which costs more than it saves and keeps the pixels of a group from being worked on side by side
+    asm volatile("" : "+v"(m5d));
+    // skip: the caller wants the pixel left as it is and passes o = 0: ratio 0 keeps the colour, and with the
+    // foreground case switched off the alpha is kept too
+    const bool o_lo = o < 3u;
+    const bool take_fg = (o > 252u) | ((b < 3u) & !skip);
+    const uint32_t m5 = o_lo ? 0u : (take_fg ? 32u : m5d);
+    const uint32_t res_opa = take_fg ? o : (o_lo ? b : opa4);
+    const uint32_t r = (((fgs - bgs) * m5) >> 5) + bgs;
+    const uint32_t folded = __builtin_amdgcn_bitop3_b32(r >> 16, r, 0x07E0u, 0xE4);      // (r >> 16 & 0x7E0) | (r & ~0x7E0); bits 16-31 are dropped below
+    return __builtin_amdgcn_perm(res_opa, folded, sel_out);
+}
+
+// The same over the group for the normal blend mode, opacity per AM: no branches, every pixel independent of its
+// neighbours.
 template <int SRC, int AM, class A>
 __device__ __forceinline__ void argb_group_normal(const A & a, uint32_t * dw, const uint32_t * sw, uint2 mk, uint32_t color)
 {
     const uint32_t opa = (uint32_t)a.raw_opa;
-    const uint32_t sel16 = a.swap ? 0x0C0C0001u : 0x0C0C0100u;  // low 16 bits, bytes exchanged for a swapped build
+    const uint32_t sel_dup = a.swap ? 0x00010001u : 0x01000100u;  // native colour in both halves of the word
+    const uint32_t sel_out = a.swap ? 0x0C040001u : 0x0C040100u;  // colour bytes as stored, alpha, zero
+    const uint32_t color_s = (color | (color << 16)) & 0x07E0F81Fu;
     uint32_t v[8], nv[8];
     argb_unpack8(dw, v);
 #pragma unroll
@@ -1243,25 +1287,20 @@ __device__ __forceinline__ void argb_group_normal(const A & a, uint32_t * dw, co
         uint32_t fg = color;
         uint32_t m = ((j < 4 ? mk.x : mk.y) >> ((j & 3) * 8)) & 0xFFu;
         src_px<SRC>(sw, j, a.swap, fg, m);
+        const uint32_t fgs = SRC == SRC_FILL ? color_s : (fg | (fg << 16)) & 0x07E0F81Fu;
         uint32_t o;
         bool skip = false;
         if(AM == AM_CONST) o = SRC == SRC_FILL ? opa : (opa >= 253u ? 255u : opa);       // :480-488 / :768-819
         else if(AM == AM_MASK) o = m;                                                     // :494-505 / :824-843
         else if(AM == AM_FILL_MASK_OPA) {                                                 // :507-528
-            skip = m == 0u;
+            skip = m == 0u;                                                               // then o = 0 as well
             o = m == 255u ? opa : (m * opa) >> 8;
         }
         else {                                                                            // :846-871
             skip = m == 0u;
             o = m >= 253u ? opa : (opa * m) >> 8;
         }
-        const uint32_t bg = __builtin_amdgcn_perm(0u, v[j], sel16);
-        const uint32_t bg_opa = (v[j] >> 16) & 0xFFu;
-        uint32_t res, res_opa;
-        px_mix_with_alpha(bg, bg_opa, fg, o, res, res_opa);
-        const uint32_t c = res_opa > 2u ? __builtin_amdgcn_perm(0u, res, sel16) : (v[j] & 0xFFFFu);  // :391
-        const uint32_t n = c | (res_opa << 16);
-        nv[j] = skip ? (v[j] & 0xFFFFFFu) : n;
+        nv[j] = argb_px_normal(v[j], fgs, o, sel_dup, sel_out, skip);
     }
     argb_pack8(nv, dw);
 }
@@ -1324,6 +1363,24 @@ __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t
     // without a per-pixel alpha and at full opacity colour and alpha are stored whatever the pixel held (:465-477, :768-790)
     const bool blended = SRC != SRC_FILL && a.raw_mode >= 1 && a.raw_mode <= 3;
     const bool need_dst = a.has_mask || a.raw_opa < 253 || blended;
+    if constexpr(SRC == SRC_FILL) {
+        if(!need_dst) {
+            // Opaque unmasked fill (:465-477): every pixel becomes {colour, opa}, a pattern of three bytes.  A 16-byte word
+            // of the frame starts 16 * word = word (mod 3) bytes into it and is one of three constants; no exchange.
+            const uint32_t c = a.swap ? px_swap16(a.color) : a.color;
+            const uint32_t p = c | ((uint32_t)a.raw_opa << 16);
+            const uint32_t d0 = p | (p << 24), d1 = (p >> 8) | (p << 16), d2 = (p >> 16) | (p << 8);
+            const int l3 = lane % 3;
+#pragma unroll
+            for(int i = 0; i < 3; i++) {
+                const uint32_t word = gw * 3u + (uint32_t)(i * 64 + lane);
+                const int ph = (l3 + i) % 3;
+                const uint4 w = ph == 0 ? make_uint4(d0, d1, d2, d0) : (ph == 1 ? make_uint4(d1, d2, d0, d1) : make_uint4(d2, d0, d1, d2));
+                if(word < n_words) store_write_once(reinterpret_cast<uint16_t *>(dst16 + word), w);
+            }
+            return;
+        }
+    }
     uint32_t dw[2][6];
     uint2 mk[2] = {make_uint2(0, 0), make_uint2(0, 0)};
     uint32_t sw[2][SrcWords<SRC>::N];
@@ -1372,7 +1429,10 @@ __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t
 #pragma unroll
     for(int i = 0; i < 3; i++) {
         const uint32_t word = gw * 3u + (uint32_t)(i * 64 + lane);
-        if(word < n_words) dst16[word] = xch[wave][i * 64 + lane];
+        if(word < n_words) {
+            if(need_dst) dst16[word] = xch[wave][i * 64 + lane];
+            else store_write_once(reinterpret_cast<uint16_t *>(dst16 + word), xch[wave][i * 64 + lane]);  // a launch that only writes
+        }
     }
 }
 
