@@ -180,10 +180,15 @@ def test_blend_modes(gpu, oracle, swap, mode):
                     assert np.array_equal(to_np(d, np.uint16), exp), (W, opa, has_src, has_mask)
 
 
+@pytest.mark.parametrize("kernel", ["k_blend_argb_rows", "k_blend_argb_dst"])
 @pytest.mark.parametrize("swap", [1, 0])
-def test_blend_argb8565_destination(gpu, oracle, swap):
+def test_blend_argb8565_destination(gpu, oracle, swap, kernel, monkeypatch):
     """screen_transp: 3-byte destination pixels, fill_argb / map_argb / lv_color_mix_with_alpha, incl. the
-    mask-row quirk of fill_argb's opaque branch and the blend modes through set_px_argb_blend."""
+    mask-row quirk of fill_argb's opaque branch and the blend modes through set_px_argb_blend.  Through the kernel that
+    takes eight pixels per lane (areas narrower than 8 pixels, rows whose last group is moved back) and through the
+    one-pixel-per-lane kernel it replaced (LVGPU_ARGB_KERNEL=px)."""
+    if kernel == "k_blend_argb_dst":
+        monkeypatch.setenv("LVGPU_ARGB_KERNEL", "px")
     rng = np.random.default_rng(321 + swap)
     N = 2
     W, H = 41, 13
@@ -212,6 +217,60 @@ def test_blend_argb8565_destination(gpu, oracle, swap):
                            mask_buf=None if mask is None else to_dev(mask), opa=opa, blend_mode=mode)
         gpu.lv_draw_sw_blend(ctx, dsc)
         assert np.array_equal(to_np(d, np.uint8), exp), (t, opa, mode, src is not None, mask is not None)
+        inter = (max(x1, cx1), max(y1, cy1), min(x2, clip[2]), min(y2, clip[3]))
+        if inter[0] <= inter[2] and inter[1] <= inter[3] and opa > 2:
+            assert gpu.last_kernel() in (kernel, "k_blend_argb_linear")
+
+
+@pytest.mark.parametrize("swap", [1, 0])
+def test_blend_argb8565_destination_wide_areas(gpu, oracle, swap):
+    """The eight-pixels-per-lane kernel on areas of every width from 1 to 40 and a few wide ones, at every byte
+    alignment of the first pixel (3 * x), with sources and masks larger than the area (strides), image sources with
+    their own alpha, and more frames than one workgroup column takes."""
+    rng = np.random.default_rng(654 + swap)
+    W, H = 230, 9
+    area = (0, 0, W - 1, H - 1)
+    widths = list(range(1, 41)) + [63, 64, 65, 201, 222]
+    for t, w in enumerate(widths):
+        N = 1 + t % 3
+        x1 = int(rng.integers(0, W - w + 1))
+        y1, y2 = int(rng.integers(0, 3)), int(rng.integers(3, H))
+        clip = (x1, y1, x1 + w - 1, y2)
+        ba = (x1 - int(rng.integers(0, 3)), y1 - int(rng.integers(0, 2)), x1 + w - 1 + int(rng.integers(0, 3)), y2 + int(rng.integers(0, 2)))
+        bw, bh = ba[2] - ba[0] + 1, ba[3] - ba[1] + 1
+        dst = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+        dst[..., 2] = rand_mask(rng, (N, H, W))
+        kind = t % 4
+        mask = rand_mask(rng, (N, bh, bw)) if t % 5 else None
+        opa = int(rng.choice(OPAS))
+        color = int(rng.integers(0, 65536))
+        exp = dst.copy()
+        if kind < 2:
+            src = rng.integers(0, 65536, (N, bh, bw), dtype=np.uint16) if kind == 1 else None
+            for f in range(N):
+                oracle.blend(exp[f], area, clip, ba, src=None if src is None else src[f], color=color,
+                             mask=None if mask is None else mask[f], opa=opa, swap=swap, screen_transp=1)
+            dsc = gpu.BlendDsc(ba, src_buf=None if src is None else to_dev(src), color=color,
+                               mask_buf=None if mask is None else to_dev(mask), opa=opa)
+        else:
+            fmt = gpu.SRC_ARGB8888 if kind == 2 else gpu.SRC_ARGB8565
+            if fmt == gpu.SRC_ARGB8888:
+                src = rng.integers(0, 1 << 32, (N, bh, bw), dtype=np.uint32)
+                src = (src & 0xFFFFFF) | (rand_mask(rng, (N, bh, bw)).astype(np.uint32) << 24)
+            else:
+                src = rng.integers(0, 256, (N, bh, bw, 3), dtype=np.uint8)
+                src[..., 2] = rand_mask(rng, (N, bh, bw))
+            # lv_draw_sw_img_decoded hands the blend a colour plane and the image's alpha as its mask (lv_draw_sw_img.c:133-136)
+            for f in range(N):
+                c16, a8 = oracle.image_split(np.ascontiguousarray(src[f]), fmt, swap)
+                oracle.blend(exp[f], area, clip, ba, src=c16.reshape(bh, bw), mask=a8.reshape(bh, bw), opa=opa, swap=swap,
+                             screen_transp=1)
+            dsc = gpu.BlendDsc(ba, src_buf=to_dev(src), opa=opa, src_format=fmt)
+        d = to_dev(dst)
+        gpu.lv_draw_sw_blend(gpu.DrawCtx(d, area, clip, color_16_swap=swap, screen_transp=1), dsc)
+        assert np.array_equal(to_np(d, np.uint8), exp), (w, kind, opa, mask is not None)
+        if opa > 2:
+            assert gpu.last_kernel() == "k_blend_argb_rows"
 
 
 @pytest.mark.parametrize("swap", [1, 0])
@@ -241,13 +300,13 @@ def test_blend_argb8565_destination_full_frames(gpu, oracle, swap):
             gpu.lv_draw_sw_blend(ctx, dsc)
             assert np.array_equal(to_np(d, np.uint8), exp), (W, t, opa, mode, src is not None, mask is not None)
             if opa > 2:
-                assert gpu.last_kernel() == ("k_blend_argb_linear" if (W * H) % 16 == 0 else "k_blend_argb_dst")
+                assert gpu.last_kernel() == ("k_blend_argb_linear" if (W * H) % 16 == 0 else "k_blend_argb_rows")
 
 
 @pytest.mark.parametrize("swap", [1, 0])
-def test_argb8565_destination_every_alpha_pair(gpu, oracle, swap):
+def test_argb8565_destination_every_alpha_pair(gpu, oracle, swap, monkeypatch):
     """lv_color_mix_with_alpha (lv_color.h:530-577) divides fg_opa * 255 by the resulting opacity; the kernels take a
-    reciprocal instead: every (destination alpha, foreground alpha) pair, through both ARGB8565 kernels."""
+    reciprocal instead: every (destination alpha, foreground alpha) pair, through the three ARGB8565 kernels."""
     rng = np.random.default_rng(5 + swap)
     H = W = 256
     area = (0, 0, W - 1, H - 1)
@@ -258,7 +317,12 @@ def test_argb8565_destination_every_alpha_pair(gpu, oracle, swap):
         src = rng.integers(0, 65536, (2, H, W), dtype=np.uint16)
         for use_src in (False, True):
             color = int(rng.integers(0, 65536))
-            for clip, kernel in ((area, "k_blend_argb_linear"), ((1, 0, W - 1, H - 1), "k_blend_argb_dst")):
+            for clip, kernel in ((area, "k_blend_argb_linear"), ((1, 0, W - 1, H - 1), "k_blend_argb_rows"),
+                                 ((1, 0, W - 1, H - 1), "k_blend_argb_dst")):
+                if kernel == "k_blend_argb_dst":
+                    monkeypatch.setenv("LVGPU_ARGB_KERNEL", "px")
+                else:
+                    monkeypatch.delenv("LVGPU_ARGB_KERNEL", raising=False)
                 exp = dst.copy()
                 for f in range(2):
                     oracle.blend(exp[f], area, clip, area, src=src[f] if use_src else None, color=color, mask=mask[f], opa=opa,

@@ -239,7 +239,7 @@ def test_list_argb8565_destination(gpu, oracle, swap, W, H, N):
         if W % 16 == 0:
             assert gpu.last_kernel() == "k_blend_list"
         else:
-            assert gpu.last_kernel() in ("k_blend_argb_dst", "k_blend_argb_linear")
+            assert gpu.last_kernel() in ("k_blend_argb_rows", "k_blend_argb_linear")
 
 
 def test_compiled_list_replay(gpu, oracle):

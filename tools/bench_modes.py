@@ -50,3 +50,14 @@ for label, dsc, bpp in (("fill, A8 mask, opa 255", lvgpu.BlendDsc(area, color=0x
     dt = timeit(lambda: bl.run())
     print("   as a one-item display list %-26s %-16s %7.3f ms %7.1f Gpx/s %6.0f GB/s" % (
         "", lvgpu.last_kernel(), dt * 1e3, px / dt / 1e9, px * bpp / dt / 1e9), flush=True)
+# the same destination through the any-rectangle kernel: the two clipped areas of bench.py's clipped_* workloads
+for (x1, y1, x2, y2) in ((3, 5, 470, 300), (11, 10, 211, 110)):
+    aw, ah = x2 - x1 + 1, y2 - y1 + 1
+    m2 = lvgpu.synth(lvgpu.SYNTH_MASK_UI, 5, 0, (N, ah, aw))
+    s2 = lvgpu.synth(lvgpu.SYNTH_U16, 6, 0, (N, ah, aw))
+    apx = N * aw * ah
+    for label, dsc, bpp in (("fill, A8 mask, opa 255", lvgpu.BlendDsc((x1, y1, x2, y2), color=0x1234, mask_buf=m2, opa=255), 7),
+                            ("RGB565 map, A8 mask, opa 200", lvgpu.BlendDsc((x1, y1, x2, y2), src_buf=s2, mask_buf=m2, opa=200), 9)):
+        dt = timeit(lambda: lvgpu.lv_draw_sw_blend(ctx3, dsc))
+        print("ARGB8565 dst, %dx%d area at x = %d: %-28s %-16s %7.3f ms %7.1f Gpx/s %6.0f GB/s (%d B/px) %4.1f %%" % (
+            aw, ah, x1, label, lvgpu.last_kernel(), dt * 1e3, apx / dt / 1e9, apx * bpp / dt / 1e9, bpp, apx * bpp / dt / 8e10), flush=True)

@@ -411,8 +411,15 @@ int launch_blend(BlendArgs & a, int fmt, hipStream_t st, bool argb_dst = false, 
             g_last_kernel = "k_blend_argb_linear";
             return dispatch_src<LaunchArgbLinear>(fmt, a, st);
         }
-        g_last_kernel = "k_blend_argb_dst";
-        return dispatch_src<LaunchArgbDst>(fmt, a, st);
+        // LVGPU_ARGB_KERNEL=px in the environment: the one-pixel-per-lane kernel instead (for measuring and for tests
+        // that compare the two; read at every call)
+        const char * e = getenv("LVGPU_ARGB_KERNEL");
+        if(e && !strcmp(e, "px")) {
+            g_last_kernel = "k_blend_argb_dst";
+            return dispatch_src<LaunchArgbDst>(fmt, a, st);
+        }
+        g_last_kernel = "k_blend_argb_rows";
+        return launch_argb_rows(fmt, a, st);
     }
     uint32_t * owned = nullptr;
     int rc = prepare_first_nb(a, st, &owned, first_nb_buf);

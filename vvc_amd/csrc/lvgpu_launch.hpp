@@ -29,6 +29,7 @@ int launch_band(int fmt, const BlendArgs & a, hipStream_t st);   // fmt: SRC_FIL
 uint32_t band_pad_of_last_launch();  // dynamic LDS the calling thread's last k_band launch asked for (diagnostics)
 int launch_tile_any(int fmt, const BlendArgs & a, hipStream_t st);
 int launch_rows(int fmt, const BlendArgs & a, hipStream_t st);
+int launch_argb_rows(int fmt, const BlendArgs & a, hipStream_t st);   // ARGB8565 destination, any rectangle
 
 #define LVGPU_LAUNCH_TRY(expr)                                                                                      \
     do {                                                                                                            \

@@ -44,8 +44,24 @@ struct LaunchRows {
     }
 };
 
+template <int SRC>
+struct LaunchArgbRows {
+    static int run(const BlendArgs & a, hipStream_t st)
+    {
+        RowsMap map;
+        memset(&map, 0, sizeof(map));
+        map.groups_per_row = ((uint32_t)a.w + 7) / 8;
+        const uint64_t lanes = (uint64_t)map.groups_per_row * (uint32_t)a.h;
+        dim3 grid((uint32_t)((lanes + 255) / 256), std::min<uint32_t>(a.n_frames, 65535));
+        hipLaunchKernelGGL(k_blend_argb_rows<SRC>, grid, dim3(256), 0, st, a, map);
+        LVGPU_LAUNCH_TRY(hipGetLastError());
+        return LVGPU_OK;
+    }
+};
+
 }  // namespace
 
 int launch_rows(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchRows>(fmt, a, st); }
+int launch_argb_rows(int fmt, const BlendArgs & a, hipStream_t st) { return dispatch_src<LaunchArgbRows>(fmt, a, st); }
 
 }  // namespace lvgpu
