@@ -19,6 +19,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
     clipped_small, clipped_large   lv_draw_sw_blend of a per-frame RGB565 image + A8 mask over a clipped,
                            misaligned area (201x101 at an odd x / 468x296 at x = 3) of 480x320 buffers; pixels
                            counted are the area's (7 B/px)
+    clipped_small_argb, clipped_large_argb   the same into a 3-byte ARGB8565 draw buffer (screen_transp):
+                           3 R + 3 W + 2 R + 1 R = 9 B/px
     fill_translucent       fill_normal without mask, translucent (premultiplied formula + scan-order pre-pass), 4 B/px
     fill_opaque / map_opaque   lv_color_fill per row (2 B/px, write only) / row copy (4 B/px)
     fill_masked            fill_normal with an A8 mask at opa 255 (5 B/px)
@@ -66,10 +68,12 @@ WORKLOADS = {
     "blend_rgb565a8": (7, 480, 320, 4096), "blend_flush_rgb565a8": (9, 480, 320, 4096), "scene": (4, 480, 320, 4096),
     "blend_flush_4k": (10, 3840, 2160, 64), "blend_flush_466": (10, 466, 466, 2048), "flush_180_466": (4, 466, 466, 2048),
     "clipped_small": (7, 480, 320, 4096), "clipped_large": (7, 480, 320, 4096),
+    "clipped_small_argb": (9, 480, 320, 4096), "clipped_large_argb": (9, 480, 320, 4096),
     "fill_translucent": (4, 480, 320, 4096), "fill_opaque": (2, 480, 320, 4096), "map_opaque": (4, 480, 320, 4096),
     "fill_masked": (5, 480, 320, 4096), "fill_masked_argb": (7, 480, 320, 4096),
 }
-CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300)}
+CLIPPED_AREAS = {"clipped_small": (11, 10, 211, 110), "clipped_large": (3, 5, 470, 300),
+                 "clipped_small_argb": (11, 10, 211, 110), "clipped_large_argb": (3, 5, 470, 300)}
 KERNEL_SOURCES = ("lvgpu.hip", "lvgpu_tiles.hip", "lvgpu_tiles_col.hip", "lvgpu_tiles_any.hip", "lvgpu_rows.hip", "lvgpu_launch.hpp", "lvgpu_kernels.hpp", "lvgpu_list.hpp",
                   "lvgpu_px.hpp")
 
@@ -399,7 +403,7 @@ def main(argv=None):
     wants_out = wl in ("blend_flush", "blend_flush_nowb", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
     if wl == "flush_180_466":
         rot = 2
-    if wl == "fill_masked_argb":
+    if wl.endswith("_argb"):
         dst = lvgpu.synth(lvgpu.SYNTH_MASK_UNI, SEED_DST, first * 3, (n, H, W, 3))
         ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap, screen_transp=1)
     else:
@@ -535,8 +539,9 @@ def main(argv=None):
         elif wl in CLIPPED_AREAS:
             ba = CLIPPED_AREAS[wl]
             desc = ("%s: lv_draw_sw_blend of a per-frame RGB565 image + A8 mask (%s) over the clipped area %s of %dx%d "
-                    "buffers, opa 255, LV_COLOR_16_SWAP %d, %d frames per GPU; pixels counted = the area's"
-                    % (wl, args.mask, list(ba), W, H, args.swap, n))
+                    "%sbuffers, opa 255, LV_COLOR_16_SWAP %d, %d frames per GPU; pixels counted = the area's"
+                    % (wl, args.mask, list(ba), W, H, "3-byte ARGB8565 (screen_transp) " if wl.endswith("_argb") else "",
+                       args.swap, n))
         elif wl.startswith("fill") or wl == "map_opaque":
             desc = ("%s: %s over whole %dx%d buffers, LV_COLOR_16_SWAP %d, %d frames per GPU"
                     % (wl, {"fill_translucent": "fill_normal, no mask, opa %d (premultiplied formula + scan-order pre-pass)" % (137 if args.swap else 103),

@@ -5,7 +5,7 @@
 #   tools/collect_profiles.sh [workload ...]       (default: every workload below; "<name>_swap0" = --swap 0)
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
-ALL="blend_flush blend_flush_swap0 blend_flush_nowb blend rotate blend_flush_rgb565a8 blend_rgb565a8 blend_flush_4k clipped_small clipped_large fill_translucent fill_opaque map_opaque fill_masked fill_masked_argb scene blend_flush_466 flush_180_466"
+ALL="blend_flush blend_flush_swap0 blend_flush_nowb blend rotate blend_flush_rgb565a8 blend_rgb565a8 blend_flush_4k clipped_small clipped_large fill_translucent fill_opaque map_opaque fill_masked fill_masked_argb clipped_large_argb clipped_small_argb scene blend_flush_466 flush_180_466"
 for w in ${@:-$ALL}; do
   name=${w%_swap0}
   extra=""

@@ -2,7 +2,7 @@
 # VALU issue share of the dominant kernel of several workloads (GPU box).
 set -o pipefail
 export TMPDIR=/tmp
-for wl in clipped_small clipped_large fill_translucent blend_flush_466 blend_flush_4k blend_flush fill_masked blend scene; do
+for wl in clipped_large_argb clipped_small_argb fill_masked_argb clipped_large; do
 OUT=gpurun_out/prof_sq/$wl
 mkdir -p $OUT
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 bench.py --workload $wl --no-cpu-baseline --no-eighth --steps 10 --warmup 3 > $OUT/log.txt 2>&1 || { tail -5 $OUT/log.txt; exit 1; }

@@ -26,7 +26,7 @@ os.makedirs(dst, exist_ok=True)
 # dominant kernel of each workload (a substring of the demangled name in rocprofv3's tables)
 KERNEL = {"blend_flush": "k_tile", "blend_flush_nowb": "k_tile", "blend": "k_blend_linear", "rotate": "k_tile", "blend_flush_rgb565a8": "k_band",
           "blend_rgb565a8": "k_blend_linear", "blend_flush_4k": "k_tile_col", "clipped_small": "k_blend_rows",
-          "clipped_large": "k_blend_rows", "fill_translucent": "k_blend_linear", "fill_opaque": "k_blend_linear",
+          "clipped_large": "k_blend_rows", "clipped_large_argb": "k_blend_argb_rows", "clipped_small_argb": "k_blend_argb_rows", "fill_translucent": "k_blend_linear", "fill_opaque": "k_blend_linear",
           "map_opaque": "k_blend_linear", "fill_masked": "k_blend_linear", "fill_masked_argb": "k_blend_argb_linear",
           "scene": "k_blend_list", "blend_flush_466": "k_tile_any", "flush_180_466": "k_flush_linear_any"}
 

@@ -1439,23 +1439,25 @@ __global__ __launch_bounds__(256) void k_blend_argb_linear(BlendArgs a, uint32_t
 // ARGB8565 destination over any rectangle, eight pixels per lane: k_blend_rows' dealing of lanes to groups row by row,
 // for pixels of three bytes.  Nothing about such a row is aligned (its first byte is at 3 * x), so every access is an
 // under-aligned wide one: 16 + 8 bytes of destination, 8 of mask, the source as in k_blend_rows.  A row's groups are
-// counted from the area's first pixel; when the width is not a multiple of 8 the last group of a row is moved back
-// so that it ends with the row -- its loads stay inside the row, it blends all eight pixels and stores only the ones
-// no other group owns (pixels j0..7), in 4-byte pieces and at most three single bytes.  Areas narrower than 8 pixels
-// are gathered and stored byte by byte.
+// counted from the area's first pixel; when the width is not a multiple of 8 the last group of a row is moved back so
+// that it ends with the row, and the pixels it shares with the group before it are blended and stored by both lanes,
+// to the same values: the two lanes are neighbours in one wavefront, whose loads all precede its stores.  That they
+// are neighbours is arranged by the numbering: a row takes an even number of lanes (map.groups_per_row, one idle lane
+// at its start when the number of groups is odd), so a row's last lane has an odd number and never starts a wavefront.
+// Areas narrower than 8 pixels are gathered and stored byte by byte.
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
-typedef uint32_t u32_a1 __attribute__((aligned(1)));
 template <int SRC>
 __global__ __launch_bounds__(256) void k_blend_argb_rows(BlendArgs a, RowsMap map)
 {
-    const uint32_t n_groups = map.groups_per_row * (uint32_t)a.h;
+    const uint32_t n_lanes = map.groups_per_row * (uint32_t)a.h;
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if(idx >= n_groups) return;
+    if(idx >= n_lanes) return;
     constexpr bool fill = SRC == SRC_FILL;
-    const uint32_t y = idx / map.groups_per_row, k = idx - y * map.groups_per_row;
+    const uint32_t y = idx / map.groups_per_row;
+    const int k = (int)(idx - y * map.groups_per_row) - (int)(map.groups_per_row - (uint32_t)(a.w + 7) / 8u);
+    if(k < 0) return;                                  // the idle lane of a row with an odd number of groups
     const bool wide = a.w >= 8;
-    const int x_lo = wide ? min((int)k * 8, a.w - 8) : 0;
-    const int j0 = wide ? (int)k * 8 - x_lo : 0, j1 = wide ? 8 : a.w;   // pixels [j0, j1) of the group are this lane's
+    const int x_lo = wide ? min(k * 8, a.w - 8) : 0;
     const bool blended = !fill && a.raw_mode >= 1 && a.raw_mode <= 3;
     const bool need_dst = a.has_mask || a.raw_opa < 253 || blended;   // else colour and alpha are stored whatever the pixel held
     // fill_argb's "only the mask matters" loop (:494-505) never adds (mask_stride - w) at the end of a row
@@ -1477,43 +1479,34 @@ __global__ __launch_bounds__(256) void k_blend_argb_rows(BlendArgs a, RowsMap ma
                 const u32x2_a1 v = *reinterpret_cast<const u32x2_a1 *>(a.mask + (long long)f * a.mask_fs + mo);
                 mk = make_uint2(v.x, v.y);
             }
-        }
-        else {
-            if(need_dst) {
-#pragma unroll
-                for(int b = 0; b < 21; b++)
-                    if(b < 3 * j1) dw[b >> 2] |= (uint32_t)dp[b] << ((b & 3) * 8);
-            }
-            if(!fill) load_src_guarded<SRC>(a.src, (long long)f * a.src_fs + so, 0, j1, sw);
-            if(a.mask) {
-                const uint8_t * mp = a.mask + (long long)f * a.mask_fs + mo;
-#pragma unroll
-                for(int j = 0; j < 7; j++)
-                    if(j < j1) {
-                        const uint32_t m = mp[j];
-                        if(j < 4) mk.x |= m << (j * 8);
-                        else mk.y |= m << ((j - 4) * 8);
-                    }
-            }
-        }
-        argb_group<SRC, true>(a, dw, sw, mk, a.color);
-        if(wide && j0 == 0) {
+            argb_group<SRC, true>(a, dw, sw, mk, a.color);
             const u32x4_a1 v0 = {dw[0], dw[1], dw[2], dw[3]};
             const u32x2_a1 v1 = {dw[4], dw[5]};
             *reinterpret_cast<u32x4_a1 *>(dp) = v0;
             *reinterpret_cast<u32x2_a1 *>(dp + 16) = v1;
         }
         else {
-            const int b0 = 3 * j0, b1 = 3 * j1;   // bytes [b0, b1) of the group
+            const int nb = 3 * a.w;                    // bytes of the row, at most 21
+            if(need_dst) {
 #pragma unroll
-            for(int i = 0; i < 6; i++) {
-                if(4 * i >= b0 && 4 * i + 4 <= b1) *reinterpret_cast<u32_a1 *>(dp + 4 * i) = dw[i];
-                else {
-#pragma unroll
-                    for(int q = 0; q < 4; q++)
-                        if(4 * i + q >= b0 && 4 * i + q < b1) dp[4 * i + q] = (uint8_t)(dw[i] >> (q * 8));
-                }
+                for(int b = 0; b < 21; b++)
+                    if(b < nb) dw[b >> 2] |= (uint32_t)dp[b] << ((b & 3) * 8);
             }
+            if(!fill) load_src_guarded<SRC>(a.src, (long long)f * a.src_fs + so, 0, a.w, sw);
+            if(a.mask) {
+                const uint8_t * mp = a.mask + (long long)f * a.mask_fs + mo;
+#pragma unroll
+                for(int j = 0; j < 7; j++)
+                    if(j < a.w) {
+                        const uint32_t m = mp[j];
+                        if(j < 4) mk.x |= m << (j * 8);
+                        else mk.y |= m << ((j - 4) * 8);
+                    }
+            }
+            argb_group<SRC, true>(a, dw, sw, mk, a.color);
+#pragma unroll
+            for(int b = 0; b < 21; b++)
+                if(b < nb) dp[b] = (uint8_t)(dw[b >> 2] >> ((b & 3) * 8));
         }
     }
 }
