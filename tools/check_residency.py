@@ -15,7 +15,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ["blend_flush", "blend", "rotate", "blend_rgb565a8", "blend_flush_rgb565a8", "fill_masked", "map_opaque", "fill_masked_argb"]
+WORKLOADS = ["blend_flush", "blend", "rotate", "blend_rgb565a8", "blend_flush_rgb565a8", "fill_masked", "map_opaque", "fill_masked_argb", "fill_translucent"]
 
 
 def run(workload, capped):

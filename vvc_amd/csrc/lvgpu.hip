@@ -296,6 +296,10 @@ struct LaunchLinear {
         const int fast = fast_path<SRC>(a);
         uint32_t pad = 0;
         if(fast_is_mix(fast)) pad = residency_pad(st, SRC == SRC_FILL ? LIN_PAD_LDS_FILL : LIN_PAD_LDS);
+        // the translucent unmasked fill has twice the instructions per byte: six workgroups per CU instead of eight gain
+        // 1.5 points (67.5 -> 69.1 % of the HBM peak), five and fewer lose (62 %, 53 %, 39 %)
+        else if(fast == FAST_PREMULT) pad = residency_pad(st, LIN_PAD_LDS_PREMULT);
+        if(const char * e = getenv("LVGPU_LIN_PAD")) pad = residency_pad(st, (uint32_t)atoi(e));   // for measuring
         // FAST_OPAQUE (opaque fill / map: write-once stores that bypass the L2) is fastest uncapped: 88 % / 77 % of peak
         hipLaunchKernelGGL(k_blend_linear<SRC>, dim3((uint32_t)blocks), dim3(256), pad, st, a, gpf, cpf);
         HIP_TRY(hipGetLastError());

@@ -18,7 +18,7 @@ int host_fail(int code, const char * text);
 // Dynamic LDS to ask for so that fewer workgroups share a CU (0 on a stream confined to some of the CUs, or with
 // LVGPU_NO_RESIDENCY_CAP in the environment); the values sit on measured plateaus, see their uses.
 constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_PAD_LDS = 32 * 1024, TILE_PAD_LDS_COPY = 20 * 1024,
-                   BAND_PAD_LDS = 40 * 1024, ARGB_PAD_LDS = 16 * 1024;
+                   BAND_PAD_LDS = 40 * 1024, ARGB_PAD_LDS = 16 * 1024, LIN_PAD_LDS_PREMULT = 24 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes);
 int tile_rows_per_phase(const char * env_name, int chosen);
 

@@ -144,19 +144,21 @@ __device__ __forceinline__ uint32_t px_mix_premult(const PremultFill & pf, uint3
 }
 
 // The same for the two native pixels held in the halves of w, in packed 16-bit arithmetic: every sum
-// pm + channel * opa_inv stays below 2^16 (opa_q + opa_inv = 255, so it is at most 63 * 255), and for t < 65535
-// LV_UDIV255(t) = (t * 0x8081) >> 23 = floor(t / 255) = (t + 1 + (t >> 8)) >> 8, which needs no 32-bit product.
+// t = pm + channel * opa_inv stays below 2^16 (opa_q + opa_inv = 255, so it is at most 63 * 255), and for such t
+// LV_UDIV255(t) = (t * 0x8081) >> 23 = floor(t / 255) = (t1 + (t1 >> 8)) >> 8 with t1 = t + 1 (checked for every t up to
+// 63 * 255), which needs no 32-bit product; the + 1 rides on the premultiplied constant.  A quotient is at most the
+// channel's maximum, so the reference's masks on the results (:514-516) change nothing and are left out.
 typedef unsigned short px_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t px_mix_premult_x2(const PremultFill & pf, uint32_t w)
 {
     auto pk = [](uint32_t v) { return __builtin_bit_cast(px_u16x2, v); };
     auto u32 = [](px_u16x2 v) { return __builtin_bit_cast(uint32_t, v); };
-    const px_u16x2 inv = pk(pf.opa_inv * 0x00010001u), one = pk(0x00010001u);
-    auto div255 = [&](px_u16x2 t) { return (px_u16x2)((t + (t >> 8) + one) >> 8); };
-    const px_u16x2 r = div255(pk((w >> 11) & 0x001F001Fu) * inv + pk(pf.pm_r * 0x00010001u));
-    const px_u16x2 g = div255(pk((w >> 5) & 0x003F003Fu) * inv + pk(pf.pm_g * 0x00010001u));
-    const px_u16x2 b = div255(pk(w & 0x001F001Fu) * inv + pk(pf.pm_b * 0x00010001u));
-    return ((u32(r) & 0x001F001Fu) << 11) | ((u32(g) & 0x003F003Fu) << 5) | (u32(b) & 0x001F001Fu);
+    const px_u16x2 inv = pk(pf.opa_inv * 0x00010001u);
+    auto div255 = [&](px_u16x2 t1) { return (px_u16x2)((t1 + (t1 >> 8)) >> 8); };
+    const px_u16x2 r = div255(pk((w >> 11) & 0x001F001Fu) * inv + pk((pf.pm_r + 1u) * 0x00010001u));
+    const px_u16x2 g = div255(pk((w >> 5) & 0x003F003Fu) * inv + pk((pf.pm_g + 1u) * 0x00010001u));
+    const px_u16x2 b = div255(pk(w & 0x001F001Fu) * inv + pk((pf.pm_b + 1u) * 0x00010001u));
+    return (u32(r) << 11) | (u32(g) << 5) | u32(b);
 }
 
 // The scan-order cache of :262-263/:279-283 in closed form: a black destination pixel that precedes the first
