@@ -204,9 +204,8 @@ __device__ __forceinline__ uint4 blend_group_mix(const A & a, uint4 d, const uin
                 src_px<SRC>(sw, p, a.swap, fg, m);
                 f = (fg | (fg << 16)) & SPREAD;
             }
-            const uint32_t o = OM == OM_CONST ? a.opa : px_opa<OM>(m, a.opa);
-            const uint32_t t = ((((f - b) * ((o + 4u) >> 3)) >> 5) + b) & SPREAD;
-            r[h] = t | (t >> 16);  // the pixel in the low half; the high half is not looked at below
+            const uint32_t t = (((f - b) * px_mix5_of<OM>(m, a.opa)) >> 5) + b;
+            r[h] = __builtin_amdgcn_bitop3_b32(t >> 16, t, 0x07E0u, 0xE4);  // (t >> 16 & 0x7E0) | (t & ~0x7E0): the pixel in the low half; the high half is not looked at below
         }
         rw[j >> 1] = __builtin_amdgcn_perm(r[1], r[0], sel_out);
     }

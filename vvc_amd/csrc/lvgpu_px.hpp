@@ -127,6 +127,17 @@ __device__ __forceinline__ uint32_t px_opa(uint32_t m, uint32_t opa)
     return opa;
 }
 
+// The 5-bit ratio lv_color_mix works with, (o + 4) >> 3, straight from the mask and the opacity for the two
+// mask-times-opacity modes: ((m * opa >> 8) + 4) >> 3 = (m * opa + 1024) >> 11 (both divisions round down), one
+// multiply-add and one shift; the mask values that take the opacity as it is select the launch-constant (opa + 4) >> 3.
+template <int OM>
+__device__ __forceinline__ uint32_t px_mix5_of(uint32_t m, uint32_t opa)
+{
+    if(OM == OM_FILL_MASK_OPA) return m == 255u ? (opa + 4u) >> 3 : (__umul24(m, opa) + 1024u) >> 11;   // v_mad_u32_u24
+    if(OM == OM_MAP_MASK_OPA) return m >= 253u ? (opa + 4u) >> 3 : (__umul24(m, opa) + 1024u) >> 11;   // m == 0 gives 0
+    return ((OM == OM_MASK ? m : opa) + 4u) >> 3;
+}
+
 // Constants of fill_normal's no-mask translucent branch (lv_draw_sw_blend.c:261-287), prepared on the host.
 struct PremultFill {
     uint32_t pm_r, pm_g, pm_b;  // lv_color_premult(color, opa_q)           (lv_color.h:474-488)
