@@ -1,4 +1,4 @@
-"""GPU, BASELINE.json's full sizes (4096 frames of 480x320 and a 3840x2160 canvas): the CPU oracle would take
+"""GPU, the benchmark's full sizes (4096 frames of 480x320 and a 3840x2160 canvas): the CPU oracle would take
 minutes there, so parity is checked through size-independent properties of the path plus an oracle check on a
 sample of frames taken from the full batch."""
 import numpy as np

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Rewrite the numeric columns (kernel us, Mpx/s, % of peak, traffic) of the results table in DESIGN.md from
-profiles/<round>/*_pmc_summary.json:  python3 tools/design_table.py r03"""
+"""Rewrite the numeric columns (kernel us, Mpx/s, % of peak, traffic) of the results table of the design notes from
+profiles/<set>/*_pmc_summary.json:  python3 tools/design_table.py r03"""
 import json
 import os
 import re

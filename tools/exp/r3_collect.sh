@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 collection (GPU box): the profile set (tools/collect_profiles.sh), the display-list profile, the off-grid
+# Collection (GPU box): the profile set (tools/collect_profiles.sh), the display-list profile, the off-grid
 # shape table, and two fuzz runs on the kernels as they are.
 set -o pipefail
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 final collection (GPU box): the GPU suite, the profile set, the display-list profile, the off-grid shape table.
+# Collection (GPU box): the GPU suite, the profile set, the display-list profile, the off-grid shape table.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/gputests.log 2>&1 || { tail -40 gpurun_out/gputests.log; exit 1; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 experiment 1 (run on the GPU box): parity of the phased quarter-turn kernels for every rows-per-phase
+# Experiment (run on the GPU box): parity of the phased quarter-turn kernels for every rows-per-phase
 # setting, then the rate sweep of tools/bench_phases.py.  Stops at the first failure.
 set -o pipefail
 O=gpurun_out/r3_phases

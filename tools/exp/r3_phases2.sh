@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 experiment 2 (GPU box): the whole GPU suite on the new launch rules, then both quarter-turn kernels on the
+# Experiment (GPU box): the whole GPU suite on the new launch rules, then both quarter-turn kernels on the
 # sizes both take (tools/bench_phases.py both), the sweep on the launcher's own choices, and the bench lines.
 set -o pipefail
 O=gpurun_out/r3_phases2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof (see tools/collect_profiles.sh) into the committed summaries under profiles/<round>/ and
+"""Turn gpurun_out/prof (see tools/collect_profiles.sh) into the committed summaries under profiles/<set>/ and
 profiles/traffic.json (HBM bytes per launch of each workload's dominant kernel, which bench.py reports as
 roofline.traffic when the kernel sources still are the ones that were profiled).
 

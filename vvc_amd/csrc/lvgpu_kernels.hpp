@@ -93,6 +93,7 @@ __device__ __forceinline__ uint32_t px_core_s(const A & a, uint32_t d, uint32_t 
     if(OM == OM_RUNTIME) return px_core(a, d, fg, m, scan_idx, fnb);
     if(OM == OM_OPAQUE) return fg;
     if(OM == OM_FILL_PREMULT) return px_fill_premult(a.pf, d, scan_idx, fnb);
+    if(!BLENDED) return px_mix5(fg, d, px_mix5_of<OM>(m, a.opa));
     const uint32_t o = OM == OM_CONST ? a.opa : px_opa<OM>(m, a.opa);
     if(BLENDED) {
         switch(a.blend_fn) {
