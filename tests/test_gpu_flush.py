@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 def quarter_turn_kernel(W, H, fused=False):
     """Heights on the 32-px grid: one tile per wavefront.  Off it, kernels that write long panel-row runs: the
     any-size kernel (workgroups sized to the height) up to 256 rows, and for the rotation alone also up to 384 and from
-    513 to 1536 rows; otherwise a 512-row column of tiles per workgroup.  Sizes off the 8-pixel grid: any-size."""
+    1025 to 1536 rows; otherwise the column kernel (a workgroup of up to sixteen wavefronts per column of tiles).  Sizes
+    off the 8-pixel grid: any-size."""
     if W % 8 or H % 8 or (H % 32 and H <= 256):
         return "k_tile_any"
-    if H % 32 and not fused and (H <= 384 or 512 < H <= 1536):
+    if H % 32 and not fused and (H <= 384 or 1024 < H <= 1536):
         return "k_tile_any"
     return "k_tile_col" if H % 32 else "k_tile"
 
@@ -21,8 +22,10 @@ def quarter_turn_kernel(W, H, fused=False):
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(480, 320), (320, 480), (100, 37), (64, 64), (72, 8), (8, 136), (1, 1), (7, 3),
                                    (96, 200), (64, 40), (200, 344), (136, 72), (8, 8), (240, 135), (135, 240), (65, 129),
-                                   # any-size kernel with 5, 6, 4 + 4, 5 + 5 and 6 + 6 + 6 wavefronts; the column kernel above
-                                   (482, 320), (481, 321), (40, 328), (33, 466), (24, 600), (16, 1080), (8, 1544)])
+                                   # any-size kernel with 5, 6, 4 + 4 and 6 + 6 + 6 wavefronts; the column kernel with 10, 14,
+                                   # 16 and 16 + 16 (nine of them idle)
+                                   (482, 320), (481, 321), (40, 328), (33, 466), (24, 600), (16, 1080), (8, 840), (16, 1000),
+                                   (8, 1544)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -93,7 +96,8 @@ def test_blend_flush_fused(gpu, oracle, rot, swap, fmt):
 
 
 @pytest.mark.parametrize("rot", [1, 3])
-@pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216), (72, 264), (64, 520)])
+@pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216), (72, 264), (64, 520), (72, 1000), (64, 1080),
+                                   (8, 1544)])
 def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
     """Heights that are not a multiple of 32 px: fused blend + rotation through the column kernels."""
     W, H = shape
@@ -249,7 +253,7 @@ def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape,fmt", [((480, 320), 2), ((480, 320), 1), ((480, 328), 2), ((200, 96), 1), ((135, 240), 2),
-                                       ((466, 30), 4), ((64, 64), 0), ((3840, 24), 2)])
+                                       ((466, 30), 4), ((64, 64), 0), ((3840, 24), 2), ((72, 264), 2), ((64, 600), 1), ((8, 1544), 2)])
 def test_blend_flush_discard_dst(gpu, oracle, rot, shape, fmt):
     """LVGPU_BLEND_FLAG_DISCARD_DST (the reference's full_refresh configuration, src/lv_port.c:241: the draw buffer is
     dead once flushed): the panel image is what the call gives without the flag, and wherever blend and flush run as one

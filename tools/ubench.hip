@@ -178,20 +178,20 @@ int main(int argc, char ** argv)
         ms = T.run([&] { hipLaunchKernelGGL((k_tile<SRC_COPY, 8, false>), dim3((n_tiles + TILE_WPB - 1) / TILE_WPB), dim3(64 * TILE_WPB), 0, 0, a, W, H, tiles_x, tiles_y, tpf, n_tiles); });
         report("k_tile<COPY> rot90 (4 B/px)", px * 4.0, ms);
     }
-    {   // the column kernel on this frame size.  480x320, rebuilt with COL_WPB = 5 (a workgroup then writes 64 whole,
-        // consecutive panel rows = 40 KB contiguous): fused 61 %, rotation alone 71 %; 8: 64 / 68 %; 10: 56 / 59 %;
+    {   // the column kernel on this frame size, 5 / 8 / 10 wavefronts per workgroup (5: a workgroup writes 64 whole,
+        // consecutive panel rows = 40 KB contiguous).  480x320: fused 61 / 64 / 56 %, rotation alone 71 / 68 / 59 %;
         // k_tile: 70 / 74 % -- contiguous output is not what the fused kernel is short of
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * COL_WPB - 1) / (TILE * COL_WPB);
-        const uint32_t n_blocks = tiles_x * cols_y * n_frames;
         a.rot = 1;
         char name[96];
-        for(uint32_t pad = 0; pad <= 64 * 1024; pad += 16 * 1024) {
-            const uint32_t lds = pad > 64u * 8 * COL_WPB * 16 ? pad - 64u * 8 * COL_WPB * 16 : 0;
-            snprintf(name, sizeof name, "k_tile_col<ARGB8888> WPB %d fused (10 B/px), +%u KB LDS", COL_WPB, lds / 1024);
-            float ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_ARGB8888, 8, false>), dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
+        for(int wpb : {5, 8, 10}) {
+            const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
+            const uint32_t n_blocks = tiles_x * cols_y * n_frames;
+            const uint32_t lds = 8192u * wpb;
+            snprintf(name, sizeof name, "k_tile_col<ARGB8888> WPB %d fused (10 B/px)", wpb);
+            float ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_ARGB8888, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb); });
             report(name, px * 10.0, ms);
-            snprintf(name, sizeof name, "k_tile_col<COPY> WPB %d rot90 (4 B/px), +%u KB LDS", COL_WPB, lds / 1024);
-            ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_COPY, 4, false>), dim3(n_blocks), dim3(64 * COL_WPB), lds, 0, a, W, H, tiles_x, cols_y, n_blocks); });
+            snprintf(name, sizeof name, "k_tile_col<COPY> WPB %d rot90 (4 B/px)", wpb);
+            ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_COPY, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb); });
             report(name, px * 4.0, ms);
         }
     }

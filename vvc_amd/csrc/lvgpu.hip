@@ -339,7 +339,14 @@ struct LaunchArgbLinear {
 };
 // Panel rows of a 90/270-degree output are 2*H bytes long: with H % 32 != 0 they start off 64-byte boundaries and
 // the tile kernel's 128-byte output runs degrade; the column kernel writes 1-KB runs.
-inline bool wants_col(const BlendArgs & a) { return (a.h % 32) != 0; }
+inline bool wants_col(const BlendArgs & a)
+{
+    if(const char * e = getenv("LVGPU_QT_KERNEL")) {   // a switch for measuring, see tile_ok
+        if(e[0] == 'c') return true;
+        if(e[0] == 't') return false;
+    }
+    return (a.h % 32) != 0;
+}
 
 // LVGPU_NO_BAND in the environment keeps masked fused launches on the tile kernel: tools/bench_fused_src.py uses it to
 // compare the two on the machine at hand.
@@ -372,18 +379,18 @@ bool tile_ok(const BlendArgs & a, int fmt)
 {
     // Heights off the 32-pixel grid: which of the two kernels that write long panel-row runs is ahead was measured.
     // With the blend fused in, k_tile_any up to 256 rows (one run per panel row: 320x200 68 against 63 % of peak), the
-    // eight-wave k_tile_col above (480x328 63 against 53 %, 1080p 64 against 56 %).  The rotation alone stays with
-    // k_tile_any, whose workgroups are sized to the height, wherever k_tile_col's 512-row workgroups would be idle for
-    // a good part: up to 384 rows (480x272 68 against 63 %) and from 513 to 1536 (1024x600 62 against 54 %, 1080p 64
-    // against 61 %); from 385 to 512 rows and on 4K canvases k_tile_col is level or ahead (464x464 66 against 64 %).
+    // k_tile_col above (480x328 67 against 53 %, 1080p 64 against 56 %).  The rotation alone stays with k_tile_any up to
+    // 384 rows (level with k_tile_col there) and from 1025 to 1536 rows (1080p: 67 against 64 %); from 385 to 1024 rows,
+    // where one k_tile_col workgroup takes a column of the frame whole, and on 4K canvases k_tile_col is ahead
+    // (1024x600 71 against 64 %, 1280x720 70 against 66 %, 3840x2160 67 against 65 %).
     if((a.h % 32) != 0) {
-        // LVGPU_QT_KERNEL=any|col in the environment (read at every call) overrides the choice: a switch for measuring
+        // LVGPU_QT_KERNEL=any|col|tile in the environment (read at every call) overrides the choice: a switch for measuring
         if(const char * e = getenv("LVGPU_QT_KERNEL")) {
             if(e[0] == 'a') return false;
         }
         else {
             if(a.h <= 256) return false;
-            if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 512 && a.h <= 1536))) return false;
+            if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 1024 && a.h <= 1536))) return false;
         }
     }
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;

@@ -549,19 +549,25 @@ __global__ __launch_bounds__(64 * TILE_WPB) void k_tile(BlendArgs a, int W, int 
 // ---------------------------------------------------------------------------------------------------------------
 // k_tile_col: k_tile for frames whose height is not a multiple of 32 pixels.  There the panel rows (2*H bytes each)
 // start on 32/64/96-byte offsets within a 128-byte line, a single tile's 128-byte output runs fall apart into two
-// pieces, and pieces below 64 bytes are written at a fraction of the full-line rate.  Here the COL_WPB wavefronts of a
-// workgroup take vertically adjacent tiles (64 columns x 64*COL_WPB rows), exchange their transposed blocks through
-// the workgroup's LDS, and every wavefront then writes whole panel-row runs of 128*COL_WPB bytes, one run per store
-// instruction (64 lanes x 16 bytes): only the first and the last line of a run are partial.
+// pieces, and pieces below 64 bytes are written at a fraction of the full-line rate.  Here the wpb wavefronts of a
+// workgroup (chosen at launch, 1 to 16; 8 KB of dynamic LDS each) take vertically adjacent tiles (64 columns x 64*wpb
+// rows), exchange their transposed blocks through the workgroup's LDS, and every wavefront then writes whole panel-row
+// runs of 128*wpb bytes (64 lanes x 16 bytes per store instruction): only the first and the last line of a run are
+// partial, and up to 1024 rows one workgroup writes whole panel rows, which follow each other in memory.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int COL_WPB = 8;  // 5 to 7 (fewer empty tile slots on 4K, 1080p) and 16 measured slower: the run length counts
+constexpr int COL_WPB_MAX = 16;
+// most wavefronts per workgroup for NR rows per phase: with the whole block per phase the blend needs more than the 128
+// registers a lane of a 16-wavefront workgroup may have
+constexpr int col_wpb_max(int nr) { return nr == 8 ? 8 : COL_WPB_MAX; }
 template <int SRC, int NR, bool DISCARD>
-__global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, uint32_t n_blocks)
+__global__ __launch_bounds__(64 * col_wpb_max(NR)) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
 {
-    __shared__ uint4 lds[64 * 8 * COL_WPB];   // [panel row of the block 0..63][chunk of the run 0..8*COL_WPB-1], swizzled
+    extern __shared__ uint4 lds[];   // [panel row of the block 0..63][chunk of the run 0..8*wpb-1], swizzled
+    const int RUN = 8 * wpb;         // 16-byte chunks per output run
+    const int TH = TILE * wpb;       // rows of the block
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);  // gridDim.x == n_blocks
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t bpf = tiles_x * cols_y;
     const uint32_t f = blk / bpf;
     const uint32_t t = blk - f * bpf;
@@ -569,11 +575,10 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
     // still in L2 (3840x2160: rotation alone 60.7 -> 63.8 %, fused 64.1 -> 64.8 % against row-major block order)
     const uint32_t tx = t / cols_y, cy = t - tx * cols_y;
     constexpr bool BLEND = SRC != SRC_COPY;
-    constexpr int RUN = 8 * COL_WPB;                           // 16-byte chunks per output run
     const bool r90 = a.rot == 1;
 
     const int bx = lane & 7, by = lane >> 3;
-    const int Y0 = (int)cy * TILE * COL_WPB;                   // first source row of the block
+    const int Y0 = (int)cy * TH;                               // first source row of the block
     const int x0 = tx * TILE + bx * 8, y0 = Y0 + wave * TILE + by * 8;
     const bool inside = x0 < W && y0 < H;                      // H % 8 == 0: a lane's 8 rows are inside or outside together
     if(inside) {
@@ -618,16 +623,18 @@ __global__ __launch_bounds__(64 * COL_WPB) void k_tile_col(BlendArgs a, int W, i
     if(a.out) {
         uint16_t * out = a.out + (long long)f * a.out_fs;
         // first pixel of the run within its panel row; negative for the last block of a column, whose run sticks out
-        const int run0 = r90 ? H - Y0 - TILE * COL_WPB : Y0;
+        const int run0 = r90 ? H - Y0 - TH : Y0;
+        // chunk q = (k * wpb + wave) * 64 + lane of the block's 64 x RUN chunks lies in panel row q / RUN = 8 k + xl0
+        const int u = wave * 8 + (lane >> 3), xl0 = u / wpb;
+        const int qc = (u - xl0 * wpb) * 8 + (lane & 7);
+        const int px = run0 + qc * 8;
 #pragma unroll
-        for(int k = 0; k < (64 * RUN) / (64 * COL_WPB); k++) {   // rows per wavefront: 64 rows x RUN chunks over all lanes
-            const int q = (k * COL_WPB + wave) * 64 + lane;      // chunk number within the block's 64 x RUN output
-            const int xl = q / RUN;
+        for(int k = 0; k < 8; k++) {
+            const int xl = k * 8 + xl0;
             const int X = tx * TILE + xl;
-            const int px = run0 + (q - xl * RUN) * 8;
             if(X < W && px >= 0 && px + 8 <= H) {
                 const int R = r90 ? X : W - 1 - X;
-                store_streaming(out + (size_t)R * H + (size_t)px, lds[xl * RUN + ((q - xl * RUN) ^ (xl >> 3))]);
+                store_streaming(out + (size_t)R * H + (size_t)px, lds[xl * RUN + (qc ^ (xl >> 3))]);
             }
         }
     }
@@ -936,9 +943,12 @@ __device__ __forceinline__ void store_group_masked_any(uint16_t * p, uint4 r, ui
 // frame height with as few idle wavefronts as possible; up to 512 rows one workgroup takes a column of tiles whole
 // and writes complete panel rows, which follow each other in memory.  The exchange area is 8 KB of dynamic LDS per
 // wavefront: [panel row of the region 0..63][chunk of the run 0..8*wpb-1], swizzled.
-constexpr int ANY_WPB_MAX = 8;
+constexpr int ANY_WPB_MAX = 16;
+// most wavefronts per workgroup for NR rows per phase: with the whole block per phase the blend needs more than the 128
+// registers a lane of a 16-wavefront workgroup may have
+constexpr int any_wpb_max(int nr) { return nr == 8 ? 8 : ANY_WPB_MAX; }
 template <int SRC, int NR, bool DISCARD>
-__global__ __launch_bounds__(64 * ANY_WPB_MAX) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
+__global__ __launch_bounds__(64 * any_wpb_max(NR)) void k_tile_any(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
 {
     extern __shared__ uint4 lds[];
     const int RUN = 8 * wpb;               // 16-byte chunks per output run

@@ -41,7 +41,7 @@ struct LaunchTileAny {
             // five tiles of height, blend fused in: six wavefronts (three workgroups per CU) are ahead of five (four per CU)
             if(SRC != SRC_COPY && nr < 8 && tiles_y == 5) wpb = 6;
         }
-        if(const char * e = getenv("LVGPU_ANY_WPB")) wpb = std::min(std::max(atoi(e), 1), ANY_WPB_MAX);
+        if(const char * e = getenv("LVGPU_ANY_WPB")) wpb = std::min(std::max(atoi(e), 1), any_wpb_max(nr));
         const uint32_t cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
         const uint32_t tiles_x = (W + TILE - 1) / TILE;
         const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;

@@ -1,5 +1,6 @@
 // lvgpu_tiles_col.hip -- launch of k_tile_col (a translation unit of its own: see lvgpu_launch.hpp).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -12,20 +13,44 @@ struct LaunchTileCol {
     static int run(const BlendArgs & a, hipStream_t st)
     {
         const int W = a.w, H = a.h;
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * COL_WPB - 1) / (TILE * COL_WPB);
+        // Wavefronts per workgroup and rows per phase (tools/exp/r3_col_wpb.py; LVGPU_COL_WPB and LVGPU_COL_NR override).
+        // A workgroup takes 64 * wpb rows of a 64-pixel column of the frame.  Up to 1024 rows one workgroup as high as
+        // the frame writes whole panel rows, which follow each other in memory: with eight-wavefront workgroups a
+        // column of 600 rows is two workgroups, six of whose sixteen wavefronts have nothing to load, and every panel row
+        // is written as two runs -- 1024x600 fused 58.6 -> 67.9 % of the HBM peak, 1280x720 61.4 -> 68.2 %, 720x720
+        // 55.9 -> 65.2 %; the rotation alone 54.9 -> 70.7 %, 59.1 -> 70.2 %, 55.6 -> 65.4 %.  Above 1024 rows: the count
+        // from 9 to 16 that leaves the fewest idle wavefronts over a column (1080p: 9, fused 63.9 -> 64.8 %), and 16 on
+        // the highest frames, where the longer runs count for more than the idle wavefronts (3840x2160: rotation alone
+        // 64.6 -> 66.9 %, without the write-back 66.0 -> 67.7 %, fused 64.8 -> 64.9 %).
+        //   Rows per phase: workgroups above eight wavefronts cannot have the whole block per phase (its blend needs more
+        // than their 128 registers per lane) and nothing is lost by that: 4 rows per phase (88 registers) are level with
+        // or ahead of 8 wherever both can run (1080p 64.8 against 63.9 %, 4K level); without the write-back 2 rows per
+        // phase are ahead by up to a point.  With the write-back, frames of up to 512 rows keep eight wavefronts, two
+        // workgroups to a CU (480x272: 67.5 against 65.1 % with five); without it a workgroup as high as the frame is ahead
+        // there too (480x272 65.1 -> 70.0 %, 360x360 66.1 -> 68.7 %).
+        const int tiles_y = (H + TILE - 1) / TILE;
+        auto fewest_idle = [tiles_y]() {
+            int best = COL_WPB_MAX, slots = 1 << 30;
+            for(int w = 9; w <= COL_WPB_MAX; w++) {
+                const int s = (tiles_y + w - 1) / w * w;
+                if(s <= slots) { slots = s; best = w; }
+            }
+            return best;
+        };
+        const int wpb_tall = tiles_y <= COL_WPB_MAX ? tiles_y : (tiles_y > 24 ? COL_WPB_MAX : fewest_idle());
+        const int nr_chosen = SRC == SRC_COPY ? 4 : (a.discard_dst ? 2 : 4);
+        const int nr = tile_rows_per_phase("LVGPU_COL_NR", nr_chosen);
+        int wpb = (SRC != SRC_COPY && !a.discard_dst && tiles_y <= 8) ? 8 : wpb_tall;
+        wpb = std::min(wpb, col_wpb_max(nr));
+        if(const char * e = getenv("LVGPU_COL_WPB")) wpb = std::min(std::max(atoi(e), 1), col_wpb_max(nr));
+        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
         const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
         if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
-        const dim3 grid((uint32_t)n_blocks), block(64 * COL_WPB);
-        // Rows per phase (tools/bench_phases.py; LVGPU_COL_NR overrides).  With the blend fused in, 8 rows per phase need
-        // 145 registers and a CU holds one workgroup: fine while most of its eight wavefronts have rows to work on
-        // (3840x2160 64 % of peak against 62 % at 4 rows per phase, 1080p 64 against 62 %), not when a column of the
-        // frame leaves many of them idle: at 4 rows per phase (88 registers) two workgroups share a CU and 480x328 goes
-        // from 61 to 66 %, 480x272 from 53 to 66 %, 1024x600 from 52 to 58 %, 1280x720 from 58 to 60 %.  The rotation
-        // alone gains one to three points from 4 rows per phase at every height but 4K canvases, which like 2 (63 -> 65 %).
-        const int nr_chosen = SRC == SRC_COPY ? (H > 1536 ? 2 : 4) : (H <= 768 ? 4 : 8);
-        with_nr_discard<SRC>(tile_rows_per_phase("LVGPU_COL_NR", nr_chosen), a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
-            hipLaunchKernelGGL((k_tile_col<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, 0, st, a, W, H,
-                               tiles_x, cols_y, (uint32_t)n_blocks);
+        const dim3 grid((uint32_t)n_blocks), block(64 * wpb);
+        const size_t lds = (size_t)wpb * 8192;
+        with_nr_discard<SRC>(nr, a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
+            hipLaunchKernelGGL((k_tile_col<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, lds, st, a, W, H,
+                               tiles_x, cols_y, wpb);
         });
         LVGPU_LAUNCH_TRY(hipGetLastError());
         return LVGPU_OK;
