@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 def quarter_turn_kernel(W, H, fused=False):
-    """Heights on the 32-px grid: one tile per wavefront.  Off it, kernels that write long panel-row runs: the
+    """Heights that are multiples of 64 pixels (and low ones of 32): one tile per wavefront.  Otherwise kernels that write long panel-row runs: the
     any-size kernel (workgroups sized to the height) up to 256 rows, and for the rotation alone also up to 384 and from
     1025 to 1536 rows; otherwise the column kernel (a workgroup of up to sixteen wavefronts per column of tiles).  Sizes
     off the 8-pixel grid: any-size."""
@@ -16,7 +16,7 @@ def quarter_turn_kernel(W, H, fused=False):
         return "k_tile_any"
     if H % 32 and not fused and (H <= 384 or 1024 < H <= 1536):
         return "k_tile_any"
-    return "k_tile_col" if H % 32 else "k_tile"
+    return "k_tile_col" if H % 32 or (H % 64 and H > 128) else "k_tile"
 
 
 @pytest.mark.parametrize("rot", [0, 1, 2, 3])
@@ -160,7 +160,7 @@ def test_blend_flush_fused_band_kernel(gpu, oracle, rot, shape):
                                opa=opa)
             out = gpu.blend_flush(gpu.DrawCtx(d, color_16_swap=swap), dsc, rot, swap_bytes=1 - swap)
             # the band kernel takes the plain mix (opacity at or above the threshold); everything else stays with the tiles
-            assert gpu.last_kernel() == ("k_band(fused)" if W <= 512 and opa == 255 else "k_tile(fused)")
+            assert gpu.last_kernel() == ("k_band(fused)" if W <= 512 and opa == 255 else quarter_turn_kernel(W, H, fused=True) + "(fused)")
             assert np.array_equal(to_np(d, np.uint16), exp), (swap, fmt, opa)
             got = to_np(out, np.uint16).reshape(N, -1)
             for f in range(N):
