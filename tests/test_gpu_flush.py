@@ -25,7 +25,7 @@ def quarter_turn_kernel(W, H, fused=False):
                                    # any-size kernel with 5, 6, 4 + 4 and 6 + 6 + 6 wavefronts; the column kernel with 10, 14,
                                    # 16 and 16 + 16 (nine of them idle)
                                    (482, 320), (481, 321), (40, 328), (33, 466), (24, 600), (16, 1080), (8, 840), (16, 1000),
-                                   (8, 1544)])
+                                   (8, 1544), (10, 1000), (21, 601)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -209,7 +209,7 @@ def test_rotate_against_lvgl_own_sw_rotate(gpu, swap):
 
 @pytest.mark.parametrize("rot", [1, 3])
 @pytest.mark.parametrize("shape", [(100, 37), (135, 240), (65, 129), (7, 3), (1, 1), (466, 30), (9, 513), (64, 520),
-                                   (481, 321), (33, 466), (172, 320)])
+                                   (481, 321), (33, 466), (172, 320), (20, 1021), (12, 700)])
 def test_blend_flush_fused_any_size(gpu, oracle, rot, shape):
     """A quarter-turn flush of frames off the 8-pixel grid is still one pass with the blend (k_tile_any): every source
     kind, both byte orders, the translucent fill with its scan-order rule, frames whose stride leaves every frame at

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The quarter-turn flush, alone and fused with the blend, over frame sizes off the 32-pixel grid (run on the GPU box):
+# The quarter-turn flush, alone and fused with the blend, over frame sizes off the 64-pixel grid (run on the GPU box):
 # one line per size with the launcher's own choice of kernel and workgroup size, then, with SWEEP=1 in the environment,
 # the same sizes with LVGPU_ANY_WPB = 2..8 wavefronts per workgroup of k_tile_any (the measurements its launch rule
 # in vvc_amd/csrc/lvgpu_tiles.hip was derived from).  Output: gpurun_out/any_shapes.log, one bench_summary line each.
@@ -14,7 +14,8 @@ run() { # label, environment assignment, bench arguments...
 }
 SIZES=("466 466 2048" "454 454 2048" "390 390 4096" "360 360 4096" "240 135 16384" "135 240 16384" "320 172 8192" "172 320 8192"
        "240 240 8192" "128 160 16384" "80 160 32768" "320 200 8192" "481 321 4096" "482 320 4096" "480 322 4096" "480 272 4096"
-       "480 328 4096" "464 464 2048" "1024 600 1024" "1280 720 512" "1920 1080 256" "3840 2160 64")
+       "480 328 4096" "464 464 2048" "1024 600 1024" "1280 720 512" "1920 1080 256" "3840 2160 64"
+       "640 480 2048" "800 480 2048" "720 720 1024" "1280 800 512" "2560 1440 128" "1023 600 1024" "1278 718 512")
 for wl in rotate blend_flush; do
   for wh in "${SIZES[@]}"; do
     set -- $wh

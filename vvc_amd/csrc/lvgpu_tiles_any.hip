@@ -27,7 +27,13 @@ struct LaunchTileAny {
         // 481x321 49 -> 60 %, 480x322 53 -> 65 %, 482x320 58 -> 62 %, 390x390 50 -> 59 %.  Frames of up to four tiles
         // of height keep 8 rows per phase (320x172 67 against 66 %, 320x200 68 against 65 %, 240x135 and 240x240 level).
         const int tiles_y = (H + TILE - 1) / TILE;
-        const int nr = tile_rows_per_phase("LVGPU_ANY_NR", SRC == SRC_COPY ? (H > 400 ? 2 : 8) : (tiles_y <= 4 ? 8 : 2));
+        //   From 9 to 16 tiles of height (513 to 1024 rows) one workgroup takes a column of the frame whole, as the column
+        // kernel does: 1024x600 fused 57 -> 66 % (10 wavefronts, 4 rows per phase), rotation alone 62 -> 69 %; 1280x720
+        // fused 59 -> 65 %.  Such workgroups cannot have the whole block per phase (128 registers per lane).
+        // The rotation alone only while two such workgroups fit a CU's LDS (up to 10 wavefronts: 1023x600 55 -> 65 %;
+        // with 12, one workgroup per CU, 1278x718 falls from 61 to 53 % and 722x721 from 60 to 49 %).
+        const bool whole_column = tiles_y >= 9 && tiles_y <= (SRC == SRC_COPY ? 10 : ANY_WPB_MAX);
+        const int nr = tile_rows_per_phase("LVGPU_ANY_NR", SRC == SRC_COPY ? (H > 400 ? 2 : 8) : (tiles_y <= 4 ? 8 : (whole_column ? 4 : 2)));
         static const int order_copy[6] = {6, 5, 4, 3, 7, 8}, order_blend8[2] = {4, 3}, order_blend[5] = {6, 8, 7, 5, 4};
         const int * order = SRC == SRC_COPY ? order_copy : (nr == 8 ? order_blend8 : order_blend);
         const int n_order = SRC == SRC_COPY ? 6 : (nr == 8 ? 2 : 5);
@@ -40,6 +46,7 @@ struct LaunchTileAny {
             }
             // five tiles of height, blend fused in: six wavefronts (three workgroups per CU) are ahead of five (four per CU)
             if(SRC != SRC_COPY && nr < 8 && tiles_y == 5) wpb = 6;
+            if(whole_column && nr < 8) wpb = tiles_y;
         }
         if(const char * e = getenv("LVGPU_ANY_WPB")) wpb = std::min(std::max(atoi(e), 1), any_wpb_max(nr));
         const uint32_t cols_y = (H + TILE * wpb - 1) / (TILE * wpb);

@@ -40,7 +40,8 @@ struct LaunchTileCol {
         const int wpb_tall = tiles_y <= COL_WPB_MAX ? tiles_y : (tiles_y > 24 ? COL_WPB_MAX : fewest_idle());
         const int nr_chosen = SRC == SRC_COPY ? 4 : (a.discard_dst ? 2 : 4);
         const int nr = tile_rows_per_phase("LVGPU_COL_NR", nr_chosen);
-        int wpb = (SRC != SRC_COPY && !a.discard_dst && tiles_y <= 8) ? 8 : wpb_tall;
+        // (up to three tiles of height four wavefronts do as well as eight and leave fewer idle: 80x160 51 -> 58 %)
+        int wpb = (SRC != SRC_COPY && !a.discard_dst && tiles_y <= 8) ? (tiles_y <= 3 ? 4 : 8) : wpb_tall;
         wpb = std::min(wpb, col_wpb_max(nr));
         if(const char * e = getenv("LVGPU_COL_WPB")) wpb = std::min(std::max(atoi(e), 1), col_wpb_max(nr));
         const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
