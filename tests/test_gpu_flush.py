@@ -380,3 +380,32 @@ def test_band_kernel_without_its_residency_pad(gpu, oracle, monkeypatch):
         for f in range(N):
             assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, 1, 0))
     assert pads[1] == 0 and pads[0] in (0, 40 * 1024)   # 0 on a stream confined to some CUs or with LVGPU_NO_RESIDENCY_CAP
+
+
+@pytest.mark.parametrize("limit", [65536, 40960, 8192])
+def test_tall_frames_where_a_workgroup_gets_less_lds(gpu, oracle, monkeypatch, limit):
+    """The column and any-size kernels size a workgroup to the frame height, 8 KB of LDS per wavefront and up to 128 KB;
+    on a device (or runtime) that allows a workgroup less, they take fewer wavefronts per workgroup and more workgroups
+    per column.  Rotation alone and fused, an aligned and an unaligned frame of 600 to 1000 rows."""
+    monkeypatch.setenv("LVGPU_MAX_LDS_PER_BLOCK", str(limit))
+    rng = np.random.default_rng(limit)
+    for (W, H) in ((24, 600), (21, 601), (16, 1000)):
+        N = 2
+        area = (0, 0, W - 1, H - 1)
+        frames = rng.integers(0, 65536, (N, H, W), dtype=np.uint16)
+        for rot in (1, 3):
+            got = to_np(gpu.flush_rotate(to_dev(frames), rot), np.uint16).reshape(N, -1)
+            assert gpu.last_kernel() == quarter_turn_kernel(W, H)
+            for f in range(N):
+                assert np.array_equal(got[f], oracle.flush_frame(frames[f], W, H, rot, 0)), (W, H, rot)
+            src = rng.integers(0, 1 << 32, (N, H, W), dtype=np.uint32)
+            exp = frames.copy()
+            for f in range(N):
+                oracle.img_blend(exp[f], area, area, area, src[f], gpu.SRC_ARGB8888, 255, 1, W)
+            d = to_dev(frames)
+            out = gpu.blend_flush(gpu.DrawCtx(d), gpu.BlendDsc(area, src_buf=to_dev(src), opa=255, src_format=gpu.SRC_ARGB8888), rot)
+            assert gpu.last_kernel() == quarter_turn_kernel(W, H, fused=True) + "(fused)"
+            assert np.array_equal(to_np(d, np.uint16), exp)
+            got = to_np(out, np.uint16).reshape(N, -1)
+            for f in range(N):
+                assert np.array_equal(got[f], oracle.flush_frame(exp[f], W, H, rot, 0)), (W, H, rot)

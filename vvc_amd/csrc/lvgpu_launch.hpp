@@ -21,6 +21,7 @@ constexpr uint32_t LIN_PAD_LDS = 48 * 1024, LIN_PAD_LDS_FILL = 32 * 1024, TILE_P
                    BAND_PAD_LDS = 40 * 1024, ARGB_PAD_LDS = 16 * 1024, LIN_PAD_LDS_PREMULT = 24 * 1024;
 uint32_t residency_pad(hipStream_t st, uint32_t pad_bytes);
 int tile_rows_per_phase(const char * env_name, int chosen);
+size_t max_lds_per_block();   // the most LDS (static + dynamic) one workgroup may ask for on the current device
 
 // One launch each; fmt is a SrcFmt (SRC_COPY: rotation alone).  Shapes are checked by the callers (tile_ok, ...).
 int launch_tile(int fmt, const BlendArgs & a, hipStream_t st);

@@ -20,6 +20,24 @@ int tile_rows_per_phase(const char * name, int chosen)
     return chosen;
 }
 
+// The most LDS one workgroup may ask for on the current device (static + dynamic), looked up once per device.
+// LVGPU_MAX_LDS_PER_BLOCK in the environment (bytes; read at every call) stands in for it: a switch for tests that
+// the band kernel's residency pad is dropped where it does not fit.
+size_t max_lds_per_block()
+{
+    if(const char * e = getenv("LVGPU_MAX_LDS_PER_BLOCK")) return (size_t)atoll(e);
+    static thread_local int dev_cached = -1;
+    static thread_local size_t cached = 0;
+    int dev = -1, v = 0;
+    if(hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
+    if(dev != dev_cached) {
+        if(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+        cached = (size_t)v;
+        dev_cached = dev;
+    }
+    return cached;
+}
+
 namespace {
 
 thread_local uint32_t g_band_pad_last = 0;  // what the last k_band launch of this thread asked for beyond its static LDS
@@ -44,24 +62,6 @@ struct LaunchTile {
         return LVGPU_OK;
     }
 };
-// The most LDS one workgroup may ask for on the current device (static + dynamic), looked up once per device.
-// LVGPU_MAX_LDS_PER_BLOCK in the environment (bytes; read at every call) stands in for it: a switch for tests that
-// the band kernel's residency pad is dropped where it does not fit.
-size_t max_lds_per_block()
-{
-    if(const char * e = getenv("LVGPU_MAX_LDS_PER_BLOCK")) return (size_t)atoll(e);
-    static thread_local int dev_cached = -1;
-    static thread_local size_t cached = 0;
-    int dev = -1, v = 0;
-    if(hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
-    if(dev != dev_cached) {
-        if(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
-        cached = (size_t)v;
-        dev_cached = dev;
-    }
-    return cached;
-}
-
 template <int SRC>
 int launch_band_src(const BlendArgs & a, hipStream_t st)
 {

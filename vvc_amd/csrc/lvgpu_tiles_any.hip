@@ -48,6 +48,7 @@ struct LaunchTileAny {
             if(SRC != SRC_COPY && nr < 8 && tiles_y == 5) wpb = 6;
             if(whole_column && nr < 8) wpb = tiles_y;
         }
+        wpb = std::max(1, std::min(wpb, (int)(max_lds_per_block() / 8192)));   // 8 KB of LDS per wavefront
         if(const char * e = getenv("LVGPU_ANY_WPB")) wpb = std::min(std::max(atoi(e), 1), any_wpb_max(nr));
         const uint32_t cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
         const uint32_t tiles_x = (W + TILE - 1) / TILE;

@@ -43,6 +43,7 @@ struct LaunchTileCol {
         // (up to three tiles of height four wavefronts do as well as eight and leave fewer idle: 80x160 51 -> 58 %)
         int wpb = (SRC != SRC_COPY && !a.discard_dst && tiles_y <= 8) ? (tiles_y <= 3 ? 4 : 8) : wpb_tall;
         wpb = std::min(wpb, col_wpb_max(nr));
+        wpb = std::max(1, std::min(wpb, (int)(max_lds_per_block() / 8192)));   // 8 KB of LDS per wavefront
         if(const char * e = getenv("LVGPU_COL_WPB")) wpb = std::min(std::max(atoi(e), 1), col_wpb_max(nr));
         const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
         const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
