@@ -10,11 +10,11 @@ pytestmark = pytest.mark.gpu
 def quarter_turn_kernel(W, H, fused=False):
     """Heights that are multiples of 64 pixels (and low ones of 32): one tile per wavefront.  Otherwise kernels that write long panel-row runs: the
     any-size kernel (workgroups sized to the height) up to 256 rows, and for the rotation alone also up to 384 and from
-    1025 to 1536 rows; otherwise the column kernel (a workgroup of up to sixteen wavefronts per column of tiles).  Sizes
+    1281 to 1536 rows; otherwise the column kernel (a workgroup of up to sixteen wavefronts per column of tiles).  Sizes
     off the 8-pixel grid: any-size."""
     if W % 8 or H % 8 or (H % 32 and H <= 256):
         return "k_tile_any"
-    if H % 32 and not fused and (H <= 384 or 1024 < H <= 1536):
+    if H % 32 and not fused and (H <= 384 or 1280 < H <= 1536):
         return "k_tile_any"
     return "k_tile_col" if H % 32 or (H % 64 and H > 128) else "k_tile"
 
@@ -25,7 +25,7 @@ def quarter_turn_kernel(W, H, fused=False):
                                    # any-size kernel with 5, 6, 4 + 4 and 6 + 6 + 6 wavefronts; the column kernel with 10, 14,
                                    # 16 and 16 + 16 (nine of them idle)
                                    (482, 320), (481, 321), (40, 328), (33, 466), (24, 600), (16, 1080), (8, 840), (16, 1000),
-                                   (8, 1544), (10, 1000), (21, 601)])
+                                   (8, 1544), (10, 1000), (21, 601), (8, 1200), (8, 1304)])
 @pytest.mark.parametrize("swap_bytes", [0, 1])
 def test_flush_rotate(gpu, oracle, rot, shape, swap_bytes):
     W, H = shape
@@ -97,7 +97,7 @@ def test_blend_flush_fused(gpu, oracle, rot, swap, fmt):
 
 @pytest.mark.parametrize("rot", [1, 3])
 @pytest.mark.parametrize("shape", [(480, 328), (64, 40), (200, 8), (136, 216), (72, 264), (64, 520), (72, 1000), (64, 1080),
-                                   (8, 1544)])
+                                   (8, 1544), (8, 1272)])
 def test_blend_flush_fused_strip_kernel(gpu, oracle, rot, shape):
     """Heights that are not a multiple of 32 px: fused blend + rotation through the column kernels."""
     W, H = shape

@@ -188,10 +188,10 @@ int main(int argc, char ** argv)
             const uint32_t n_blocks = tiles_x * cols_y * n_frames;
             const uint32_t lds = 8192u * wpb;
             snprintf(name, sizeof name, "k_tile_col<ARGB8888> WPB %d fused (10 B/px)", wpb);
-            float ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_ARGB8888, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb); });
+            float ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_ARGB8888, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb, 1); });
             report(name, px * 10.0, ms);
             snprintf(name, sizeof name, "k_tile_col<COPY> WPB %d rot90 (4 B/px)", wpb);
-            ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_COPY, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb); });
+            ms = T.run([&] { hipLaunchKernelGGL((k_tile_col<SRC_COPY, 4, false>), dim3(n_blocks), dim3(64 * wpb), lds, 0, a, W, H, tiles_x, cols_y, wpb, 1); });
             report(name, px * 4.0, ms);
         }
     }

@@ -384,9 +384,9 @@ bool tile_ok(const BlendArgs & a, int fmt)
     // Heights off the 32-pixel grid: which of the two kernels that write long panel-row runs is ahead was measured.
     // With the blend fused in, k_tile_any up to 256 rows (one run per panel row: 320x200 68 against 63 % of peak), the
     // k_tile_col above (480x328 67 against 53 %, 1080p 64 against 56 %).  The rotation alone stays with k_tile_any up to
-    // 384 rows (level with k_tile_col there) and from 1025 to 1536 rows (1080p: 67 against 64 %); from 385 to 1024 rows,
-    // where one k_tile_col workgroup takes a column of the frame whole, and on 4K canvases k_tile_col is ahead
-    // (1024x600 71 against 64 %, 1280x720 70 against 66 %, 3840x2160 67 against 65 %).
+    // 384 rows (level with k_tile_col there) and from 1281 to 1536 rows; from 385 to 1280 rows, where one k_tile_col
+    // workgroup takes a column of the frame whole, and on 4K canvases k_tile_col is ahead (1024x600 71 against 64 %,
+    // 1280x720 70 against 66 %, 1080p 69 against 67 %, 3840x2160 67 against 65 %).
     if((a.h % 32) != 0) {
         // LVGPU_QT_KERNEL=any|col|tile in the environment (read at every call) overrides the choice: a switch for measuring
         if(const char * e = getenv("LVGPU_QT_KERNEL")) {
@@ -394,7 +394,7 @@ bool tile_ok(const BlendArgs & a, int fmt)
         }
         else {
             if(a.h <= 256) return false;
-            if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 1024 && a.h <= 1536))) return false;
+            if(fmt == SRC_COPY && (a.h <= 384 || (a.h > 1280 && a.h <= 1536))) return false;
         }
     }
     return linear_ok(a, fmt) && (a.w % 8) == 0 && (a.h % 8) == 0;

@@ -559,12 +559,15 @@ constexpr int COL_WPB_MAX = 16;
 // most wavefronts per workgroup for NR rows per phase: with the whole block per phase the blend needs more than the 128
 // registers a lane of a 16-wavefront workgroup may have
 constexpr int col_wpb_max(int nr) { return nr == 8 ? 8 : COL_WPB_MAX; }
+// tpw (1, 2 or 4): tiles per wavefront, one after the other (wavefront w takes tiles w, w + wpb, ...), so that a
+// workgroup can be as high as a frame of more than 16 tiles while its LDS (8 KB per tile) allows.
 template <int SRC, int NR, bool DISCARD>
-__global__ __launch_bounds__(64 * col_wpb_max(NR)) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb)
+__global__ __launch_bounds__(64 * col_wpb_max(NR)) void k_tile_col(BlendArgs a, int W, int H, uint32_t tiles_x, uint32_t cols_y, int wpb,
+                                                                 int tpw)
 {
-    extern __shared__ uint4 lds[];   // [panel row of the block 0..63][chunk of the run 0..8*wpb-1], swizzled
-    const int RUN = 8 * wpb;         // 16-byte chunks per output run
-    const int TH = TILE * wpb;       // rows of the block
+    extern __shared__ uint4 lds[];   // [panel row of the block 0..63][chunk of the run 0..RUN-1], swizzled
+    const int RUN = 8 * wpb * tpw;   // 16-byte chunks per output run
+    const int TH = TILE * wpb * tpw; // rows of the block
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -579,16 +582,18 @@ __global__ __launch_bounds__(64 * col_wpb_max(NR)) void k_tile_col(BlendArgs a, 
 
     const int bx = lane & 7, by = lane >> 3;
     const int Y0 = (int)cy * TH;                               // first source row of the block
-    const int x0 = tx * TILE + bx * 8, y0 = Y0 + wave * TILE + by * 8;
-    const bool inside = x0 < W && y0 < H;                      // H % 8 == 0: a lane's 8 rows are inside or outside together
-    if(inside) {
-        uint16_t * dst = a.dst + (long long)f * a.dst_fs;
-        const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
-        const long long src_px0 = (long long)f * a.src_fs;
-        const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
-        const int fast = fast_path<SRC>(a);
+    const int x0 = tx * TILE + bx * 8;
+    uint16_t * dst = a.dst + (long long)f * a.dst_fs;
+    const uint8_t * mask = a.mask ? a.mask + (long long)f * a.mask_fs : nullptr;
+    const long long src_px0 = (long long)f * a.src_fs;
+    const uint32_t fnb = a.first_nb ? a.first_nb[f] : 0xFFFFFFFFu;
+    const int fast = fast_path<SRC>(a);
+    for(int s = 0; s < tpw; s++) {
+        const int tile = wave + s * wpb;                       // this wavefront's s-th tile of the block
+        const int y0 = Y0 + tile * TILE + by * 8;
+        if(x0 >= W || y0 >= H) continue;                       // H % 8 == 0: a lane's 8 rows are inside or outside together
         // position of this lane's 8 rows in the run, in ascending panel address order
-        const int c = r90 ? RUN - 1 - (wave * 8 + by) : wave * 8 + by;
+        const int c = r90 ? RUN - 1 - (tile * 8 + by) : tile * 8 + by;
         uint4 * col0 = &lds[bx * 8 * RUN + (c ^ bx)];          // column j of the block: chunk (bx*8 + j) * RUN + (c ^ bx)
 #pragma unroll
         for(int ph = 0; ph < 8 / NR; ph++) {
@@ -624,17 +629,20 @@ __global__ __launch_bounds__(64 * col_wpb_max(NR)) void k_tile_col(BlendArgs a, 
         uint16_t * out = a.out + (long long)f * a.out_fs;
         // first pixel of the run within its panel row; negative for the last block of a column, whose run sticks out
         const int run0 = r90 ? H - Y0 - TH : Y0;
-        // chunk q = (k * wpb + wave) * 64 + lane of the block's 64 x RUN chunks lies in panel row q / RUN = 8 k + xl0
-        const int u = wave * 8 + (lane >> 3), xl0 = u / wpb;
-        const int qc = (u - xl0 * wpb) * 8 + (lane & 7);
+        // pass k of the workgroup stores the chunks (k * wpb + wave) * 64 + lane of the block's 64 x RUN, i.e. 8 / tpw
+        // panel rows: chunk qc of panel row k * 8 / tpw + xl0
+        const int v = wave * 64 + lane, xl0 = v / RUN;
+        const int qc = v - xl0 * RUN;
         const int px = run0 + qc * 8;
-#pragma unroll
-        for(int k = 0; k < 8; k++) {
-            const int xl = k * 8 + xl0;
-            const int X = tx * TILE + xl;
-            if(X < W && px >= 0 && px + 8 <= H) {
-                const int R = r90 ? X : W - 1 - X;
-                store_streaming(out + (size_t)R * H + (size_t)px, lds[xl * RUN + (qc ^ (xl >> 3))]);
+        const int rows_per_pass = 8 / tpw;
+        if(px >= 0 && px + 8 <= H) {
+            for(int k = 0; k < 8 * tpw; k++) {
+                const int xl = k * rows_per_pass + xl0;
+                const int X = tx * TILE + xl;
+                if(X < W) {
+                    const int R = r90 ? X : W - 1 - X;
+                    store_streaming(out + (size_t)R * H + (size_t)px, lds[xl * RUN + (qc ^ (xl >> 3))]);
+                }
             }
         }
     }

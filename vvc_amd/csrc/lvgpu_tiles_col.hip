@@ -38,21 +38,34 @@ struct LaunchTileCol {
             return best;
         };
         const int wpb_tall = tiles_y <= COL_WPB_MAX ? tiles_y : (tiles_y > 24 ? COL_WPB_MAX : fewest_idle());
-        const int nr_chosen = SRC == SRC_COPY ? 4 : (a.discard_dst ? 2 : 4);
+        const bool two_tiles = tiles_y > COL_WPB_MAX && (size_t)tiles_y * 8192 <= max_lds_per_block();   // see tpw below
+        const int nr_chosen = SRC == SRC_COPY ? 4 : (a.discard_dst && !two_tiles ? 2 : 4);
         const int nr = tile_rows_per_phase("LVGPU_COL_NR", nr_chosen);
         // (up to three tiles of height four wavefronts do as well as eight and leave fewer idle: 80x160 51 -> 58 %)
         int wpb = (SRC != SRC_COPY && !a.discard_dst && tiles_y <= 8) ? (tiles_y <= 3 ? 4 : 8) : wpb_tall;
         wpb = std::min(wpb, col_wpb_max(nr));
         wpb = std::max(1, std::min(wpb, (int)(max_lds_per_block() / 8192)));   // 8 KB of LDS per wavefront
         if(const char * e = getenv("LVGPU_COL_WPB")) wpb = std::min(std::max(atoi(e), 1), col_wpb_max(nr));
-        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb - 1) / (TILE * wpb);
+        // Frames of 17 to 20 tiles of height (1080p, 1600x1200): still one workgroup per column, its wavefronts taking two
+        // tiles each, one after the other, where the device's LDS holds the column (8 KB per tile, 136 to 160 KB):
+        // 1080p fused 64.8 -> 67.6 %, rotation alone 64.2 -> 69.5 %, without the write-back 65.9 -> 69.7 %; 1600x1200
+        // 66.0 -> 67.4 %, 65.3 -> 69.5 %, 66.7 -> 68.9 %.  Higher frames, which need more than one workgroup per column
+        // either way, gain nothing from it (3840x2160, 2560x1440), lower ones lose (1280x720 68.1 -> 66.4 %).
+        int tpw = 1;
+        if(tiles_y > COL_WPB_MAX && (size_t)tiles_y * 8192 <= max_lds_per_block() && nr < 8 && !getenv("LVGPU_COL_WPB")) {
+            tpw = 2;
+            wpb = (tiles_y + 1) / 2;
+        }
+        if(const char * e = getenv("LVGPU_COL_TPW")) tpw = atoi(e) == 2 ? 2 : (atoi(e) == 4 ? 4 : 1);   // for measuring
+        if((size_t)wpb * tpw * 8192 > max_lds_per_block()) tpw = 1;
+        const uint32_t tiles_x = (W + TILE - 1) / TILE, cols_y = (H + TILE * wpb * tpw - 1) / (TILE * wpb * tpw);
         const uint64_t n_blocks = (uint64_t)tiles_x * cols_y * a.n_frames;
         if(n_blocks > 0x7FFFFFFFull) return host_fail(LVGPU_ERR_ARG, "batch too large for one launch");
         const dim3 grid((uint32_t)n_blocks), block(64 * wpb);
-        const size_t lds = (size_t)wpb * 8192;
+        const size_t lds = (size_t)wpb * tpw * 8192;
         with_nr_discard<SRC>(nr, a.discard_dst != 0, [&](auto nr_c, auto discard_c) {
             hipLaunchKernelGGL((k_tile_col<SRC, decltype(nr_c)::value, decltype(discard_c)::value>), grid, block, lds, st, a, W, H,
-                               tiles_x, cols_y, wpb);
+                               tiles_x, cols_y, wpb, tpw);
         });
         LVGPU_LAUNCH_TRY(hipGetLastError());
         return LVGPU_OK;
