@@ -70,6 +70,9 @@ def main():
         swap = int(rng.integers(0, 2))
         W = int(rng.choice([8, 16, 64, 72, 128, 200, 320, 480])) if rng.random() < 0.7 else int(rng.integers(1, 300))
         H = int(rng.choice([1, 8, 33, 64, 96, 128, 240, 264, 328])) if rng.random() < 0.7 else int(rng.integers(1, 200))
+        if rng.random() < 0.08:   # tall, narrow frames: workgroups of 9 to 16 wavefronts, two tiles per wavefront
+            H = int(rng.choice([520, 600, 601, 648, 720, 840, 1000, 1021, 1080, 1200, 1272, 1304, 1544]))
+            W = int(rng.choice([8, 16, 24, 64, 72])) if rng.random() < 0.7 else int(rng.integers(1, 80))
         N = int(rng.integers(1, 4))
         area = (0, 0, W - 1, H - 1)
         it = _rand_item(rng, W, H, N, bool(rng.integers(0, 2)))
