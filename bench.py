@@ -94,6 +94,9 @@ def parse(argv=None):
     ap.add_argument("--mask", default="ui", choices=["ui", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eighth", action="store_true", help="skip the 32-CU (1/8 of the CUs) measurement")
+    ap.add_argument("--placement", default="spread", choices=["spread", "compact"],
+                    help="spread: draw buffers, sources and panel images in different thirds of the device memory "
+                         "(vvc_amd/placement.py); compact: wherever the allocator puts them, one after the other")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--ref-1gpu-mpx", type=float, default=0.0,
                     help="Mpx/s of the same workload on one GPU: with --gpus N > 1 the line then carries efficiency_vs_1gpu")
@@ -399,6 +402,14 @@ def main(argv=None):
     px_per_frame = px  # pixels one frame contributes to the metric
     keep = []          # tensors the descriptors point into
 
+    # Where the buffers lie: the device memory has three regions of 96 GB, and a launch that works on buffers in different
+    # regions runs faster (vvc_amd/placement.py).  Draw buffers first, then the sources and masks, then the panel images,
+    # each group pushed into the next region by ballast that is freed again before the first launch.
+    spacer = None
+    if args.placement == "spread":
+        from vvc_amd.placement import RegionSpacer
+        spacer = RegionSpacer()
+
     out = None
     wants_out = wl in ("blend_flush", "blend_flush_nowb", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
     if wl == "flush_180_466":
@@ -409,9 +420,8 @@ def main(argv=None):
     else:
         dst = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
         ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap)
-    if wants_out:
-        out_shape = (n, W, H) if rot in (1, 3) else (n, H, W)
-        out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
+    if spacer is not None:
+        spacer.next_region()
 
     dsc, blist, rec = None, None, None
     if wl in ("blend_flush", "blend_flush_nowb", "blend", "blend_flush_4k", "blend_flush_466"):
@@ -455,6 +465,14 @@ def main(argv=None):
             dscs.append(lvgpu.BlendDsc(r["area"], src_buf=s16, color=r["color"], mask_buf=m8, opa=r["opa"],
                                        blend_mode=r["blend_mode"]))
         blist = lvgpu.BlendList(ctx, dscs).compile(flush=True, rotation=rot, swap_bytes=swap_bytes)  # planned once
+
+    if spacer is not None:
+        spacer.next_region()
+    if wants_out:
+        out_shape = (n, W, H) if rot in (1, 3) else (n, H, W)
+        out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
+    if spacer is not None:
+        spacer.close()
 
     # the descriptor is marshalled once: the clipped-area kernels finish faster than Python fills a ctypes struct
     prepared = None
@@ -528,6 +546,33 @@ def main(argv=None):
                             copy_on=lambda st: lvgpu.flush_rotate(dst, 0, out=cp_out, stream=st.value))
         torch.cuda.synchronize()
 
+    # beside the spread placement: the same launch on buffers the allocator places one after the other (what a host gets
+    # that does not care), outside the timed region and only in the full default run
+    compact_ms = None
+    if rank == 0 and world == 1 and spacer is not None and not args.no_eighth and wl in ("blend_flush", "blend", "rotate"):
+        try:
+            d2 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
+            o2 = torch.empty(out.shape, dtype=torch.int16, device="cuda") if wants_out else None
+            if wl == "rotate":
+                def fn2():
+                    lvgpu.flush_rotate(d2, rot, swap_bytes=swap_bytes, out=o2)
+            else:
+                s2 = lvgpu.synth(argb_kind, SEED_SRC, first, (n, H, W))
+                dsc2 = lvgpu.BlendDsc(area, src_buf=s2, opa=255, src_format=lvgpu.SRC_ARGB8888)
+                ctx2 = lvgpu.DrawCtx(d2, color_16_swap=args.swap)
+                p2 = lvgpu.PreparedBlend(ctx2, dsc2, rot, swap_bytes, o2) if wants_out else lvgpu.PreparedBlend(ctx2, dsc2)
+                fn2 = p2.run
+            fn2()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                fn2()
+            c1.record()
+            torch.cuda.synchronize()
+            compact_ms = c0.elapsed_time(c1) / 10
+        except (RuntimeError, lvgpu.LvgpuError) as e:
+            print("bench.py: compact-placement comparison skipped: %s" % e, file=sys.stderr)
+
     if rank == 0:
         total_px = px_per_frame * n * world * args.steps
         launch_s = ev_ms / 1e3 / args.steps  # HIP events on the launch stream around the timed steps
@@ -576,6 +621,8 @@ def main(argv=None):
             "config": {
                 "workload": desc,
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
+                "placement": ("draw buffers, sources and panel images " + spacer.describe())
+                if spacer is not None else "buffers wherever the allocator puts them",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -585,6 +632,9 @@ def main(argv=None):
             },
             "pct_hbm_peak": round(100 * achieved / HBM_PEAK_GBS, 2),
         }
+        if compact_ms is not None:
+            res["roofline"]["compact_placement_launch_ms"] = round(compact_ms, 4)
+            res["roofline"]["compact_placement_frac"] = round(bpp * px_per_frame * n / (compact_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
         if copy_gbs is not None:
             res["roofline"]["measured_copy_GBs"] = round(copy_gbs, 1)
             res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)

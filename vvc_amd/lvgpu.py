@@ -394,8 +394,12 @@ _SYNTH_DTYPE = {SYNTH_U16: torch.int16, SYNTH_MASK_UI: torch.uint8, SYNTH_MASK_U
                 SYNTH_ARGB_UI: torch.int32, SYNTH_ARGB_UNI: torch.int32}
 
 
-def synth(kind, seed, first_index, shape, device="cuda", stream=None):
-    out = torch.empty(shape, dtype=_SYNTH_DTYPE[kind], device=device)
+def synth(kind, seed, first_index, shape, device="cuda", stream=None, out=None):
+    """Synthetic input of `shape`; `out`: a tensor of that shape and the kind's dtype to fill instead of a new one."""
+    if out is None:
+        out = torch.empty(shape, dtype=_SYNTH_DTYPE[kind], device=device)
+    else:
+        assert tuple(out.shape) == tuple(shape) and out.dtype == _SYNTH_DTYPE[kind] and out.is_contiguous()
     check(_lib.lib().lvgpu_synth(out.data_ptr(), kind, seed, first_index, out.numel(), _stream(stream)))
     return out
 
