@@ -403,41 +403,52 @@ def main(argv=None):
     keep = []          # tensors the descriptors point into
 
     # Where the buffers lie: the device memory has three regions of 96 GB, and a launch that works on buffers in different
-    # regions runs faster (vvc_amd/placement.py).  Draw buffers first, then the sources and masks, then the panel images,
-    # each group pushed into the next region by ballast that is freed again before the first launch.
-    spacer = None
+    # regions runs faster (vvc_amd/placement.py).  Draw buffers in one, sources and masks in another, panel images in the
+    # third, all carved out of one arena whose region boundaries are found by timing first.
+    arena, arena_note = None, "buffers wherever the allocator puts them"
     if args.placement == "spread":
-        from vvc_amd.placement import RegionSpacer
-        spacer = RegionSpacer()
+        from vvc_amd.placement import RegionArena
+        try:
+            arena = RegionArena().calibrate(lvgpu)
+        except RuntimeError as e:   # too little free memory (another rank or process on this device)
+            arena_note += " (no arena: %s)" % str(e).split("\n")[0]
+
+    def new_buf(shape, dtype, region):
+        if arena is not None:
+            try:
+                return arena.empty(shape, dtype, region)
+            except RuntimeError:
+                pass
+        return torch.empty(shape, dtype=dtype, device="cuda")
+
+    def new_synth(kind, seed, first_index, shape, region):
+        return lvgpu.synth(kind, seed, first_index, shape, out=new_buf(shape, lvgpu._SYNTH_DTYPE[kind], region))
 
     out = None
     wants_out = wl in ("blend_flush", "blend_flush_nowb", "blend_flush_rgb565a8", "blend_flush_4k", "blend_flush_466", "flush_180_466", "rotate", "scene")
     if wl == "flush_180_466":
         rot = 2
     if wl.endswith("_argb"):
-        dst = lvgpu.synth(lvgpu.SYNTH_MASK_UNI, SEED_DST, first * 3, (n, H, W, 3))
+        dst = new_synth(lvgpu.SYNTH_MASK_UNI, SEED_DST, first * 3, (n, H, W, 3), 0)
         ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap, screen_transp=1)
     else:
-        dst = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
+        dst = new_synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W), 0)
         ctx = lvgpu.DrawCtx(dst, color_16_swap=args.swap)
-    if spacer is not None:
-        spacer.next_region()
-
     dsc, blist, rec = None, None, None
     if wl in ("blend_flush", "blend_flush_nowb", "blend", "blend_flush_4k", "blend_flush_466"):
-        src = lvgpu.synth(argb_kind, SEED_SRC, first, (n, H, W))
+        src = new_synth(argb_kind, SEED_SRC, first, (n, H, W), 1)
         dsc = lvgpu.BlendDsc(area, src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888,
                              flags=lvgpu.FLAG_DISCARD_DST if wl == "blend_flush_nowb" else 0)
     elif wl.endswith("rgb565a8"):  # LV_IMG_CF_RGB565A8: colour plane + A8 plane (lv_draw_sw_img.c:85-95)
-        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
-        a8 = lvgpu.synth(mask_kind, SEED_MASK, first, (n, H, W))
+        src16 = new_synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W), 1)
+        a8 = new_synth(mask_kind, SEED_MASK, first, (n, H, W), 1)
         dsc = lvgpu.BlendDsc(area, src_buf=src16, mask_buf=a8, opa=255)
     elif wl in CLIPPED_AREAS:
         ba = CLIPPED_AREAS[wl]
         bw, bh = ba[2] - ba[0] + 1, ba[3] - ba[1] + 1
         px_per_frame = bw * bh
-        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, lo * px_per_frame, (n, bh, bw))
-        a8 = lvgpu.synth(mask_kind, SEED_MASK, lo * px_per_frame, (n, bh, bw))
+        src16 = new_synth(lvgpu.SYNTH_U16, SEED_SRC, lo * px_per_frame, (n, bh, bw), 1)
+        a8 = new_synth(mask_kind, SEED_MASK, lo * px_per_frame, (n, bh, bw), 1)
         dsc = lvgpu.BlendDsc(ba, src_buf=src16, mask_buf=a8, opa=255)
     elif wl == "fill_translucent":
         # a colour / opacity pair for which lv_color_mix and lv_color_mix_premult disagree on black (about one pair in
@@ -447,10 +458,10 @@ def main(argv=None):
     elif wl == "fill_opaque":
         dsc = lvgpu.BlendDsc(area, color=0x1234, opa=255)
     elif wl == "map_opaque":
-        src16 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W))
+        src16 = new_synth(lvgpu.SYNTH_U16, SEED_SRC, first, (n, H, W), 1)
         dsc = lvgpu.BlendDsc(area, src_buf=src16, opa=255)
     elif wl in ("fill_masked", "fill_masked_argb"):
-        a8 = lvgpu.synth(mask_kind, SEED_MASK, first, (n, H, W))
+        a8 = new_synth(mask_kind, SEED_MASK, first, (n, H, W), 1)
         dsc = lvgpu.BlendDsc(area, color=0x1234, mask_buf=a8, opa=255)
     elif wl == "scene":
         assert (W, H) == (480, 320), "the recorded scenes are 480x320"
@@ -466,13 +477,9 @@ def main(argv=None):
                                        blend_mode=r["blend_mode"]))
         blist = lvgpu.BlendList(ctx, dscs).compile(flush=True, rotation=rot, swap_bytes=swap_bytes)  # planned once
 
-    if spacer is not None:
-        spacer.next_region()
     if wants_out:
         out_shape = (n, W, H) if rot in (1, 3) else (n, H, W)
-        out = torch.empty(out_shape, dtype=torch.int16, device="cuda")
-    if spacer is not None:
-        spacer.close()
+        out = new_buf(out_shape, torch.int16, 2)
 
     # the descriptor is marshalled once: the clipped-area kernels finish faster than Python fills a ctypes struct
     prepared = None
@@ -549,7 +556,7 @@ def main(argv=None):
     # beside the spread placement: the same launch on buffers the allocator places one after the other (what a host gets
     # that does not care), outside the timed region and only in the full default run
     compact_ms = None
-    if rank == 0 and world == 1 and spacer is not None and not args.no_eighth and wl in ("blend_flush", "blend", "rotate"):
+    if rank == 0 and world == 1 and arena is not None and not args.no_eighth and wl in ("blend_flush", "blend", "rotate"):
         try:
             d2 = lvgpu.synth(lvgpu.SYNTH_U16, SEED_DST, first, (n, H, W))
             o2 = torch.empty(out.shape, dtype=torch.int16, device="cuda") if wants_out else None
@@ -621,8 +628,8 @@ def main(argv=None):
             "config": {
                 "workload": desc,
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
-                "placement": ("draw buffers, sources and panel images " + spacer.describe())
-                if spacer is not None else "buffers wherever the allocator puts them",
+                "placement": ("draw buffers, sources and panel images in regions 0, 1, 2 of " + arena.describe())
+                if arena is not None else arena_note,
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

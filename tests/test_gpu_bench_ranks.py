@@ -51,6 +51,18 @@ def test_a_failing_rank_fails_the_command(gpu):
     assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
 
 
+def test_placement_switch(gpu):
+    """One rank, both placements: the line says where the buffers were put; the results do not depend on it (same checksum
+    check inside bench.py either way)."""
+    for placement, words in (("spread", "-GB arena, regions"), ("compact", "wherever the allocator puts them")):
+        p = _bench("--frames-per-gpu", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-eighth",
+                   "--placement", placement)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        r = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+        assert words in r["config"]["placement"], r["config"]["placement"]
+        assert r["roofline"]["kernel"] == "k_tile(fused)" and r["value"] > 0
+
+
 def test_one_rank_over_rccl(gpu):
     """The collective calls of a multi-GPU run (barrier, max over ranks, gather of the per-rank times) over RCCL itself,
     with a world of one rank on this one GPU."""

@@ -1,20 +1,13 @@
-"""GPU: buffers that a host spreads over the three 96-GB regions of the device memory (vvc_amd/placement.py) give the
-same results as buffers the allocator packs together, the ballast that pushes them apart is given back, and a device
-too full for it is left alone.  What the spread buys in time is measured by bench.py, not asserted here."""
+"""GPU: buffers handed out by region of the device memory (vvc_amd/placement.py) give the same results as buffers the
+allocator places, do not overlap, and the arena is given back.  What the placement buys in time is measured by
+bench.py; here only that the timing sweep finds more than one region on a device that is mostly free."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-W, H, N = 480, 320, 64          # 19.7 MB of draw buffers: above the caching allocator's pooled sizes, so each is a fresh allocation
-
-
-def _inputs(gpu):
-    dst = gpu.synth(gpu.SYNTH_U16, 11, 0, (N, H, W))
-    src = gpu.synth(gpu.SYNTH_ARGB_UI, 12, 0, (N, H, W))
-    out = torch.empty((N, W, H), dtype=torch.int16, device="cuda")
-    return dst, src, out
+W, H, N = 480, 320, 64
 
 
 def _run(gpu, dst, src, out):
@@ -25,37 +18,45 @@ def _run(gpu, dst, src, out):
     return dst.cpu().numpy().copy(), out.cpu().numpy().copy()
 
 
-def test_spread_buffers_same_results_and_ballast_returned(gpu):
-    from vvc_amd.placement import RegionSpacer, REGION_BYTES
+def test_arena_regions_same_results_and_memory_returned(gpu):
+    from vvc_amd.placement import RegionArena, GB
     torch.cuda.empty_cache()
     free0, total = torch.cuda.mem_get_info()
-    if total < 3 * REGION_BYTES - (8 << 30) or total - free0 > (32 << 30):
+    if free0 < 250 * GB:
         pytest.skip("needs a 288-GB device with little in use")
-    sp = RegionSpacer()
-    dst = gpu.synth(gpu.SYNTH_U16, 11, 0, (N, H, W))
-    assert sp.next_region()
-    src = gpu.synth(gpu.SYNTH_ARGB_UI, 12, 0, (N, H, W))
-    assert sp.next_region()
-    out = torch.empty((N, W, H), dtype=torch.int16, device="cuda")
-    held = total - torch.cuda.mem_get_info()[0]
-    assert held > 2 * REGION_BYTES                      # the panel images were allocated with two regions in use
-    sp.close()
-    assert sp.regions == [0, 1, 2] and sp.skipped is None and "0/1/2" in sp.describe()
-    free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - free1 < (1 << 30)                    # the ballast is back; only the three small buffers remain
-    # the three lie far apart (the virtual addresses follow the allocation order, here: by more than 80 GB each)
-    p = [t.data_ptr() for t in (dst, src, out)]
-    assert abs(p[1] - p[0]) > (80 << 30) and abs(p[2] - p[1]) > (80 << 30)
+    _check_arena(gpu, RegionArena())              # all views of the arena die with that frame
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] > free0 - 1 * GB
+
+
+def _check_arena(gpu, arena):
+    arena.calibrate(gpu)
+    print(arena.describe())
+    assert len(arena.labels) == arena.n_slots >= 25 and arena.labels[0] == 0
+    assert len(set(arena.labels)) >= 2, arena.describe()      # the sweep saw launches inside and across a region
+    bufs = [arena.empty((N, H, W), torch.int16, 0), arena.empty((N, H, W), torch.int32, 1),
+            arena.empty((N, W, H), torch.int16, 2), arena.empty((N, H, W), torch.int16, 0)]
+    spans = sorted((b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()) for b in bufs)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))                 # no two overlap
+    assert all(b.data_ptr() % (2 << 20) == 0 for b in bufs)
+    lo, hi = arena.buf.data_ptr(), arena.buf.data_ptr() + arena.buf.numel()
+    assert all(lo <= a and b <= hi for a, b in spans)
+    # each lies in the span of its region
+    for b, r in zip(bufs, (0, 1, 2, 0)):
+        off = b.data_ptr() - lo - arena.base
+        assert arena.spans[r][0] <= off < arena.spans[r][1]
+    with pytest.raises(RuntimeError):
+        arena.empty((1 << 20, 1 << 10, 1 << 8), torch.uint8, 1)               # 256 TB
+    dst, src, out = bufs[:3]
+    gpu.synth(gpu.SYNTH_U16, 11, 0, (N, H, W), out=dst)
+    gpu.synth(gpu.SYNTH_ARGB_UI, 12, 0, (N, H, W), out=src)
     got = _run(gpu, dst, src, out)
-    exp = _run(gpu, *_inputs(gpu))
+    exp = _run(gpu, gpu.synth(gpu.SYNTH_U16, 11, 0, (N, H, W)), gpu.synth(gpu.SYNTH_ARGB_UI, 12, 0, (N, H, W)),
+               torch.empty((N, W, H), dtype=torch.int16, device="cuda"))
     assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1])
 
 
-def test_full_device_is_left_alone(gpu):
-    from vvc_amd.placement import RegionSpacer
-    free0 = torch.cuda.mem_get_info()[0]
-    sp = RegionSpacer(keep_free=1 << 50)                # as if everything free were spoken for
-    assert sp.next_region() is False and sp.skipped and len(sp.regions) == 2 and sp.regions[0] == sp.regions[1]
-    sp.close()
-    assert torch.cuda.mem_get_info()[0] > free0 - (64 << 20)   # nothing taken (close also empties the allocator's cache)
-    assert "too full" in sp.describe()
+def test_a_device_with_too_little_free_memory_raises(gpu):
+    from vvc_amd.placement import RegionArena
+    with pytest.raises(RuntimeError, match="GB free"):
+        RegionArena(min_bytes=1 << 50)

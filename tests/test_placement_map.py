@@ -1,0 +1,33 @@
+"""The region map of vvc_amd/placement.py without a GPU: how launch times become regions, and regions spans to allocate from."""
+from vvc_amd.placement import RegionArena, GB
+
+
+def _arena(labels):
+    a = object.__new__(RegionArena)
+    a.n_slots, a.labels = len(labels), list(labels)
+    a._set_runs()
+    return a
+
+
+def test_split_needs_two_classes_of_times():
+    assert RegionArena._split({0: 1.00, 1: 1.01, 2: 1.03}) is None
+    slow, fast = RegionArena._split({0: 1.10, 1: 1.09, 2: 1.01, 3: 1.02, 4: 1.11})
+    assert sorted(slow) == [0, 1, 4] and sorted(fast) == [2, 3]
+
+
+def test_spans_are_the_longest_runs_less_their_edge_slots():
+    a = _arena([0] * 12 + [1] * 12 + [2] * 9)
+    S = RegionArena.SLOT
+    assert a.spans == {0: [1 * S, 11 * S], 1: [13 * S, 23 * S], 2: [25 * S, 32 * S]}
+    # a stray slot inside a region does not move it; short runs keep their ends
+    b = _arena([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2])
+    assert b.spans[0] == [5 * S, 9 * S] and b.spans[1] == [10 * S, 13 * S] and b.spans[2] == [13 * S, 15 * S]
+
+
+def test_a_missing_region_takes_half_of_the_longest_span():
+    a = _arena([0] * 10 + [1] * 20)
+    S = RegionArena.SLOT
+    assert a.spans[0] == [1 * S, 9 * S]
+    assert a.spans[1][0] == 11 * S and a.spans[2][1] == 29 * S and a.spans[1][1] == a.spans[2][0]
+    assert (a.spans[1][1] - a.spans[1][0]) == 9 * S
+    assert a._next == {r: a.spans[r][0] for r in (0, 1, 2)} and GB == 1 << 30

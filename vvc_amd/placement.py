@@ -1,68 +1,163 @@
 """Host-side memory layout for the MI355X's 288 GB: which third of the device memory a buffer lies in matters.
 
-The 36-GB HBM3E stacks are twelve dies high; the device's physical address space falls into three regions of 96 GB
-(boundaries at exactly 96 and 192 GB of a fresh device), and a kernel that reads and writes one buffer while it writes
-another runs 8 % faster when the two lie in different regions: the fused blend + quarter turn over 4096 frames of
-480x320 at 75.6 % of the HBM peak instead of 70.1 % with the draw buffers and the panel images 96 GB or more apart, 76.7 %
-with the images in the third region (measured with all three carved out of one 264-GB allocation at swept offsets:
-tools/exp/r3_placement3.py).  Inside a region, and whatever the distance below 96 GB, the rate does not move.
+The device memory behaves as three regions of 96 GB, and a kernel that reads one buffer while it writes another runs
+8 % faster when the two lie in different regions: the fused blend + quarter turn over 4096 frames of 480x320 at 75.6 %
+of the HBM peak instead of 70.1 % with the draw buffers and the panel images in different regions, 76.7 % with the
+sources in the third (measured with all three carved out of one 264-GB allocation at swept offsets:
+tools/exp/r3_placement3.py).  Inside a region the distance between the buffers changes nothing.
 
-A process cannot ask the driver for physical addresses, but the driver fills the device memory from one end, so how
-much of it is in use when a buffer is allocated stands in for where the buffer lands.  RegionSpacer pushes the next
-allocations of a host into the next region with a ballast allocation and frees all ballast at the end: the buffers
-stay where they are (the rate holds after the release and after other data has been written into the freed space:
-tools/exp/r3_placement4.py), and no memory is kept.  Where the device is too full for that the spacer does nothing.
+A process cannot ask the driver for physical addresses, and where separate allocations land depends on what earlier
+processes left behind.  RegionArena therefore takes nearly all of the free device memory in ONE allocation, finds the
+region boundaries inside it by timing (calibrate(): the fused launch with its panel images moved through the arena in
+8-GB steps; a third of a second), and hands out buffers by region:
 
-    sp = RegionSpacer()
-    dst = torch.empty(...)          # region of the draw buffers
-    sp.next_region()
-    src = torch.empty(...)          # sources and masks
-    sp.next_region()
-    out = torch.empty(...)          # panel images
-    sp.close()
+    arena = RegionArena()
+    arena.calibrate(lvgpu)
+    dst = arena.empty((n, H, W), torch.int16, region=0)      # draw buffers
+    src = arena.empty((n, H, W), torch.int32, region=1)      # sources and masks
+    out = arena.empty((n, W, H), torch.int16, region=2)      # panel images
+
+A device with less than `min_bytes` free raises RuntimeError from the constructor: the caller then lives with the
+allocator's placement.
 """
 import torch
 
-REGION_BYTES = 96 << 30
+GB = 1 << 30
+ALIGN = 2 << 20
 
 
-class RegionSpacer:
-    def __init__(self, device=None, margin=3 << 30, keep_free=24 << 30):
+class RegionArena:
+    SLOT = 8 * GB            # granularity of the region map
+    PROBE_FRAMES = 2048      # 480x320 frames of the probe launch: 0.63 GB draw buffers, 1.26 GB sources, 0.63 GB images
+
+    def __init__(self, device=None, leave_free=16 * GB, min_bytes=200 * GB):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.margin, self.keep_free = margin, keep_free
-        self._ballast = []
-        self.regions = [self._used() // REGION_BYTES]   # region index the allocations made now are expected to land in
-        self.skipped = None
+        free, _total = torch.cuda.mem_get_info(self.device)
+        nbytes = (free - leave_free) // self.SLOT * self.SLOT
+        if nbytes < min_bytes:
+            raise RuntimeError("RegionArena: %.0f GB free on %s, needs %.0f" % (free / GB, self.device, (min_bytes + leave_free) / GB))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        pad = -self.buf.data_ptr() % ALIGN
+        self.base = pad
+        self.n_slots = (nbytes - pad) // self.SLOT
+        third = (self.n_slots + 2) // 3
+        self.labels = [min(i // third, 2) for i in range(self.n_slots)]   # until calibrate(): thirds of the arena
+        self.how = "assumed (thirds of the arena)"
+        self.times = None
+        self._set_runs()
 
-    def _used(self):
-        free, total = torch.cuda.mem_get_info(self.device)
-        return total - free
+    # -- carving ---------------------------------------------------------------------------------------------------
+    def view(self, offset, shape, dtype):
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        assert offset % ALIGN == 0 and offset + nbytes <= self.n_slots * self.SLOT
+        return self.buf[self.base + offset: self.base + offset + nbytes].view(dtype).view(shape)
 
-    def next_region(self):
-        """Allocate ballast up to the start of the next 96-GB region (plus a margin); False when the device is too full."""
-        torch.cuda.synchronize(self.device)
-        free, total = torch.cuda.mem_get_info(self.device)
-        used = total - free
-        target = (used // REGION_BYTES + 1) * REGION_BYTES + self.margin
-        need = target - used
-        if target >= total or need + self.keep_free > free:
-            self.skipped = "device memory too full to reach the next region (%.0f GB in use)" % (used / 2.0**30)
-            self.regions.append(used // REGION_BYTES)
-            return False
-        try:
-            self._ballast.append(torch.empty(need, dtype=torch.uint8, device=self.device))
-        except RuntimeError as e:   # includes torch.cuda.OutOfMemoryError
-            self.skipped = str(e).split("\n")[0]
-            self.regions.append(used // REGION_BYTES)
-            return False
-        self.regions.append(self._used() // REGION_BYTES)
-        return True
+    def _set_runs(self):
+        """Per region the longest run of slots with its label, less one slot at either end where the run has four or
+        more (a slot may straddle a boundary); a region without slots gets the upper half of the longest run."""
+        runs = {}
+        i = 0
+        while i < self.n_slots:
+            j = i
+            while j + 1 < self.n_slots and self.labels[j + 1] == self.labels[i]:
+                j += 1
+            if self.labels[i] not in runs or j - i > runs[self.labels[i]][1] - runs[self.labels[i]][0]:
+                runs[self.labels[i]] = (i, j)
+            i = j + 1
+        spans = {}
+        for r, (a, b) in runs.items():
+            if b - a + 1 >= 4:
+                a, b = a + 1, b - 1
+            spans[r] = [a * self.SLOT, (b + 1) * self.SLOT]
+        for r in (0, 1, 2):
+            if r not in spans:
+                big = max(spans, key=lambda k: spans[k][1] - spans[k][0])
+                lo, hi = spans[big]
+                mid = (lo + (hi - lo) // 2) // ALIGN * ALIGN
+                spans[big], spans[r] = [lo, mid], [mid, hi]
+        self.spans = spans
+        self._next = {r: spans[r][0] for r in spans}
 
-    def close(self):
-        """Free the ballast; the buffers allocated in between stay where they are."""
-        self._ballast.clear()
-        torch.cuda.empty_cache()
+    def empty(self, shape, dtype, region):
+        """An uninitialised tensor in the given region (0, 1, 2), 2-MB aligned; RuntimeError when the region is full."""
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        off = self._next[region]
+        if off + nbytes > self.spans[region][1]:
+            raise RuntimeError("RegionArena: region %d holds %.1f GB, %.1f more asked for"
+                               % (region, (self.spans[region][1] - self.spans[region][0]) / GB, nbytes / GB))
+        self._next[region] = (off + nbytes + ALIGN - 1) // ALIGN * ALIGN
+        return self.view(off, shape, dtype)
+
+    # -- the region map, by timing ------------------------------------------------------------------------------------
+    def _probe(self, lvgpu, anchor, slots):
+        """Time of three fused ARGB8888 blend + quarter-turn launches with draw buffers and sources in slot `anchor` and
+        the panel images in each of `slots` (in its upper half, so that the anchor's own slot can be probed too)."""
+        n, W, H = self.PROBE_FRAMES, 480, 320
+        a0 = anchor * self.SLOT
+        dst = self.view(a0, (n, H, W), torch.int16)
+        src = self.view(a0 + 1 * GB, (n, H, W), torch.int32)
+        ctx = lvgpu.DrawCtx(dst, color_16_swap=1)
+        dsc = lvgpu.BlendDsc((0, 0, W - 1, H - 1), src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
+        times = {}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for s in slots:
+            out = self.view(s * self.SLOT + 4 * GB, (n, W, H), torch.int16)
+            p = lvgpu.PreparedBlend(ctx, dsc, 1, 0, out)
+            p.run()
+            e0.record()
+            for _ in range(3):
+                p.run()
+            e1.record()
+            e1.synchronize()
+            times[s] = e0.elapsed_time(e1) / 3
+        return times
+
+    @staticmethod
+    def _split(times):
+        """Slots whose launch was slow (same region as the anchor) and fast; None when the times show no two classes."""
+        lo, hi = min(times.values()), max(times.values())
+        if hi < 1.04 * lo:
+            return None
+        cut = (lo * hi) ** 0.5
+        return [s for s in times if times[s] >= cut], [s for s in times if times[s] < cut]
+
+    def calibrate(self, lvgpu):
+        """Find the regions inside the arena.  Two sweeps: with the anchor in slot 0, the slots where the launch is slow
+        are slot 0's region; with the anchor in the first of the others, the slow ones among them are the second region
+        and the rest the third.  Leaves the thirds-of-the-arena map in place when the first sweep shows no structure."""
+        all_slots = list(range(self.n_slots))
+        t1 = self._probe(lvgpu, 0, all_slots)
+        self.times = [t1]
+        sp = self._split(t1)
+        if sp is None:
+            self.how = "assumed (thirds of the arena): timing showed no regions, launch times within 4 %"
+            return self
+        same0, others = sp
+        labels = [0] * self.n_slots
+        t2 = self._probe(lvgpu, others[0], others)
+        self.times.append(t2)
+        sp2 = self._split(t2)
+        if sp2 is None:
+            for s in others:
+                labels[s] = 1
+        else:
+            for s in sp2[0]:
+                labels[s] = 1
+            for s in sp2[1]:
+                labels[s] = 2
+        self.labels = labels
+        self.how = "found by timing the fused launch (%.3f / %.3f ms across / inside a region, %d frames)" % (
+            min(t1.values()), max(t1.values()), self.PROBE_FRAMES)
+        self._set_runs()
+        return self
 
     def describe(self):
-        s = "allocated in regions %s of the device memory (96 GB each), ballast freed afterwards" % "/".join(str(r) for r in self.regions)
-        return s + ("; " + self.skipped if self.skipped else "")
+        spans = ", ".join("%d: %d-%d GB" % (r, self.spans[r][0] // GB, self.spans[r][1] // GB) for r in sorted(self.spans))
+        return "one %d-GB arena, regions %s; map %s (8-GB slots), %s" % (
+            self.n_slots * self.SLOT // GB, spans, "".join(str(l) for l in self.labels), self.how)
