@@ -94,6 +94,10 @@ def parse(argv=None):
     ap.add_argument("--mask", default="ui", choices=["ui", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eighth", action="store_true", help="skip the 32-CU (1/8 of the CUs) measurement")
+    ap.add_argument("--region-map", default="auto",
+                    help="with --placement spread: 'auto' finds the memory regions inside the arena by timing (0.3 s of "
+                         "probe launches of the fused tile kernel); a map printed by `python3 -m vvc_amd.placement` on "
+                         "this device skips that, so that a kernel trace holds the workload's launches only")
     ap.add_argument("--placement", default="spread", choices=["spread", "compact"],
                     help="spread: draw buffers, sources and panel images in different thirds of the device memory "
                          "(vvc_amd/placement.py); compact: wherever the allocator puts them, one after the other")
@@ -409,7 +413,9 @@ def main(argv=None):
     if args.placement == "spread":
         from vvc_amd.placement import RegionArena
         try:
-            arena = RegionArena().calibrate(lvgpu)
+            arena = RegionArena()
+            if args.region_map == "auto" or not arena.set_map(args.region_map):
+                arena.calibrate(lvgpu)
         except RuntimeError as e:   # too little free memory (another rank or process on this device)
             arena_note += " (no arena: %s)" % str(e).split("\n")[0]
 
@@ -628,6 +634,7 @@ def main(argv=None):
             "config": {
                 "workload": desc,
                 "frames_per_gpu": n, "total_frames": n * world, "parallelism": "frames sharded, no collective",
+                "region_map": arena.map_string() if arena is not None else None,
                 "placement": ("draw buffers, sources and panel images in regions 0, 1, 2 of " + arena.describe())
                 if arena is not None else arena_note,
             },

@@ -31,3 +31,11 @@ def test_a_missing_region_takes_half_of_the_longest_span():
     assert a.spans[1][0] == 11 * S and a.spans[2][1] == 29 * S and a.spans[1][1] == a.spans[2][0]
     assert (a.spans[1][1] - a.spans[1][0]) == 9 * S
     assert a._next == {r: a.spans[r][0] for r in (0, 1, 2)} and GB == 1 << 30
+
+
+def test_a_given_map_must_fit_the_arena():
+    a = _arena([0] * 11 + [1] * 11 + [2] * 11)
+    assert not a.set_map("0" * 12 + "1" * 12) and not a.set_map("1" * 33) and not a.set_map("0" * 32 + "3")
+    assert a.labels == [0] * 11 + [1] * 11 + [2] * 11
+    m = "0" * 12 + "1" * 12 + "2" * 9
+    assert a.set_map(m) and a.map_string() == m and a.spans[2] == [25 * RegionArena.SLOT, 32 * RegionArena.SLOT]

@@ -88,8 +88,9 @@ for w in sorted(os.listdir(src)) if os.path.isdir(src) else []:
     bpp, _w0, _h0, _n0 = bench.WORKLOADS[name]
     n = line["config"]["frames_per_gpu"]
     px_launch = line["roofline"]["achieved"] * 1e9 * line["roofline"]["launch_ms"] * 1e-3 / bpp   # pixels per launch
-    summ = {"workload": w, "command": "python3 bench.py --workload %s%s --no-cpu-baseline --no-eighth" %
-            (name, " --swap 0" if w != name else ""), "config": line["config"]["workload"], "kernel": kname,
+    rmap = line["config"].get("region_map")
+    summ = {"workload": w, "command": "python3 bench.py --workload %s%s%s --no-cpu-baseline --no-eighth" %
+            (name, " --swap 0" if w != name else "", " --region-map %s" % rmap if rmap else ""), "config": line["config"]["workload"], "kernel": kname,
             "algorithmic_bytes_per_px": bpp, "algorithmic_bytes_per_launch": round(bpp * px_launch),
             "bench_launch_ms(HIP events, unprofiled-equivalent run under the kernel trace)": line["roofline"]["launch_ms"],
             "bench_frac_of_8TBs": line["roofline"]["frac"]}

@@ -157,7 +157,26 @@ class RegionArena:
         self._set_runs()
         return self
 
+    def map_string(self):
+        return "".join(str(l) for l in self.labels)
+
+    def set_map(self, s):
+        """Take a region map found earlier on this device (map_string() of an arena of the same size) instead of timing
+        again; False, and nothing changed, when it does not fit this arena."""
+        if len(s) != self.n_slots or set(s) - set("012") or s[0] != "0":
+            return False
+        self.labels = [int(c) for c in s]
+        self.how = "given (found by timing in an earlier process)"
+        self._set_runs()
+        return True
+
     def describe(self):
         spans = ", ".join("%d: %d-%d GB" % (r, self.spans[r][0] // GB, self.spans[r][1] // GB) for r in sorted(self.spans))
         return "one %d-GB arena, regions %s; map %s (8-GB slots), %s" % (
-            self.n_slots * self.SLOT // GB, spans, "".join(str(l) for l in self.labels), self.how)
+            self.n_slots * self.SLOT // GB, spans, self.map_string(), self.how)
+
+
+if __name__ == "__main__":     # python3 -m vvc_amd.placement: calibrate on device 0 and print the region map
+    from vvc_amd import lvgpu
+    lvgpu.init(0)
+    print(RegionArena().calibrate(lvgpu).map_string())
