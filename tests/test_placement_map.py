@@ -24,13 +24,29 @@ def test_spans_are_the_longest_runs_less_their_edge_slots():
     assert b.spans[0] == [5 * S, 9 * S] and b.spans[1] == [10 * S, 13 * S] and b.spans[2] == [13 * S, 15 * S]
 
 
-def test_a_missing_region_takes_half_of_the_longest_span():
-    a = _arena([0] * 10 + [1] * 20)
+def test_buffers_spill_into_other_runs_before_they_fail(monkeypatch):
+    a = _arena([0] * 10 + [1] * 20)                    # no third region in this arena
     S = RegionArena.SLOT
-    assert a.spans[0] == [1 * S, 9 * S]
-    assert a.spans[1][0] == 11 * S and a.spans[2][1] == 29 * S and a.spans[1][1] == a.spans[2][0]
-    assert (a.spans[1][1] - a.spans[1][0]) == 9 * S
-    assert a._next == {r: a.spans[r][0] for r in (0, 1, 2)} and GB == 1 << 30
+    assert a.spans == {0: [1 * S, 9 * S], 1: [11 * S, 29 * S]} and a.runs[2] == [] and GB == 1 << 30
+    got = []
+    monkeypatch.setattr(RegionArena, "view", lambda self, off, shape, dtype: got.append(off) or off)
+    import torch
+    a.empty((4 * S,), torch.uint8, 0)                  # region 0: 8 slots
+    a.empty((4 * S,), torch.uint8, 2)                  # no run of region 2: the run with most room, region 1's
+    a.empty((6 * S,), torch.uint8, 0)                  # 4 slots left in region 0: spills behind the previous one
+    assert got == [1 * S, 11 * S, 15 * S] and a.spilled == 2
+    a.empty((3 * S,), torch.uint8, 0)                  # fits region 0 again
+    assert got[-1] == 5 * S and a.spilled == 2
+    import pytest
+    with pytest.raises(RuntimeError):
+        a.empty((9 * S,), torch.uint8, 1)              # 8 slots left in region 1's run, 1 in region 0's
+    # a scrambled map: secondary runs of a region are used once its longest is full
+    b = _arena([int(c) for c in "000000000000111122222222111111221"])
+    assert b.spans == {0: [1 * S, 11 * S], 1: [25 * S, 29 * S], 2: [17 * S, 23 * S]}
+    got.clear()
+    b.empty((4 * S,), torch.uint8, 1)
+    b.empty((2 * S,), torch.uint8, 1)
+    assert got == [25 * S, 13 * S] and b.spilled == 0
 
 
 def test_a_given_map_must_fit_the_arena():

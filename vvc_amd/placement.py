@@ -56,43 +56,38 @@ class RegionArena:
         return self.buf[self.base + offset: self.base + offset + nbytes].view(dtype).view(shape)
 
     def _set_runs(self):
-        """Per region the longest run of slots with its label, less one slot at either end where the run has four or
-        more (a slot may straddle a boundary); a region without slots gets the upper half of the longest run."""
-        runs = {}
+        """Per region its runs of slots, longest first, each less one slot at either end where it has four or more (a slot
+        may straddle a boundary); spans[r] is the longest, the one buffers of region r come from first."""
+        runs = {0: [], 1: [], 2: []}
         i = 0
         while i < self.n_slots:
             j = i
             while j + 1 < self.n_slots and self.labels[j + 1] == self.labels[i]:
                 j += 1
-            if self.labels[i] not in runs or j - i > runs[self.labels[i]][1] - runs[self.labels[i]][0]:
-                runs[self.labels[i]] = (i, j)
+            a, b = (i + 1, j - 1) if j - i + 1 >= 4 else (i, j)
+            runs[self.labels[i]].append([a * self.SLOT, (b + 1) * self.SLOT, a * self.SLOT])   # lo, hi, next free byte
             i = j + 1
-        spans = {}
-        for r, (a, b) in runs.items():
-            if b - a + 1 >= 4:
-                a, b = a + 1, b - 1
-            spans[r] = [a * self.SLOT, (b + 1) * self.SLOT]
-        for r in (0, 1, 2):
-            if r not in spans:
-                big = max(spans, key=lambda k: spans[k][1] - spans[k][0])
-                lo, hi = spans[big]
-                mid = (lo + (hi - lo) // 2) // ALIGN * ALIGN
-                spans[big], spans[r] = [lo, mid], [mid, hi]
-        self.spans = spans
-        self._next = {r: spans[r][0] for r in spans}
+        for r in runs:
+            runs[r].sort(key=lambda run: run[0] - run[1])
+        self.runs = runs
+        self.spans = {r: runs[r][0][:2] for r in runs if runs[r]}
+        self.spilled = 0
 
     def empty(self, shape, dtype, region):
-        """An uninitialised tensor in the given region (0, 1, 2), 2-MB aligned; RuntimeError when the region is full."""
+        """An uninitialised tensor in the given region (0, 1, 2), 2-MB aligned.  When no run of that region has room left
+        it comes from whichever run of the arena has most (counted in `spilled`); RuntimeError when none has."""
         n = 1
         for s in shape:
             n *= s
         nbytes = n * torch.empty(0, dtype=dtype).element_size()
-        off = self._next[region]
-        if off + nbytes > self.spans[region][1]:
-            raise RuntimeError("RegionArena: region %d holds %.1f GB, %.1f more asked for"
-                               % (region, (self.spans[region][1] - self.spans[region][0]) / GB, nbytes / GB))
-        self._next[region] = (off + nbytes + ALIGN - 1) // ALIGN * ALIGN
-        return self.view(off, shape, dtype)
+        others = sorted((run for r in self.runs if r != region for run in self.runs[r]), key=lambda run: run[2] - run[1])
+        for k, run in enumerate(self.runs[region] + others):
+            if run[2] + nbytes <= run[1]:
+                off = run[2]
+                run[2] = (off + nbytes + ALIGN - 1) // ALIGN * ALIGN
+                self.spilled += k >= len(self.runs[region])
+                return self.view(off, shape, dtype)
+        raise RuntimeError("RegionArena: no run of the arena has %.1f GB left" % (nbytes / GB))
 
     # -- the region map, by timing ------------------------------------------------------------------------------------
     def _probe(self, lvgpu, anchor, slots):
@@ -172,8 +167,9 @@ class RegionArena:
 
     def describe(self):
         spans = ", ".join("%d: %d-%d GB" % (r, self.spans[r][0] // GB, self.spans[r][1] // GB) for r in sorted(self.spans))
-        return "one %d-GB arena, regions %s; map %s (8-GB slots), %s" % (
-            self.n_slots * self.SLOT // GB, spans, self.map_string(), self.how)
+        return "one %d-GB arena, regions %s; map %s (8-GB slots), %s%s" % (
+            self.n_slots * self.SLOT // GB, spans, self.map_string(), self.how,
+            "; %d buffers did not fit their region" % self.spilled if self.spilled else "")
 
 
 if __name__ == "__main__":     # python3 -m vvc_amd.placement: calibrate on device 0 and print the region map
