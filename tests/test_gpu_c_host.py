@@ -74,3 +74,33 @@ def test_multi_device_c_host_sharding(gpu, oracle, rot):
     # more devices than the machine has is an argument error, not a crash
     p = subprocess.run([MULTI, "8", "2", "99"], capture_output=True, timeout=60)
     assert p.returncode == 1 and b"bad arguments" in p.stderr
+
+
+ARENA = os.path.join(ROOT, "examples", "region_arena")
+
+
+def test_c_host_places_its_buffers_by_region(gpu, oracle):
+    """examples/region_arena.c: one arena, the memory regions inside it found by timing, the batch run with one buffer
+    per region and with all three in one: the same checksums either way, and the oracle's.  The rates it prints are
+    not asserted (256 frames are too few to show them; `examples/region_arena` without arguments runs 4096)."""
+    import torch
+    if not os.path.exists(ARENA):
+        pytest.fail("examples/region_arena is not built (make -C examples; __graft_entry__.build() does it)")
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] < (100 << 30):
+        pytest.skip("needs 100 GB of free device memory")
+    n, W, H = 256, 480, 320
+    p = subprocess.run([ARENA, str(n)], capture_output=True, timeout=170)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    vals = dict(line.split(" ", 1) for line in p.stdout.decode().strip().splitlines())
+    assert len(vals["map"]) == int(vals["arena_gb"]) // 8 and set(vals["map"]) <= set("012") and vals["map"][0] == "0"
+    px = W * H
+    dst = oracle.synth(oracle.SYNTH_U16, 0x5EED0001, 0, n * px)
+    src = oracle.synth(oracle.SYNTH_ARGB_UI, 0x5EED0002, 0, n * px)
+    panel = np.empty(n * px, np.uint16)
+    oracle.argb_blend_flush_batch(dst, src, panel, W, H, n, 1, 1, 4)
+    for placement in ("by_region", "one_region"):
+        assert int(vals["draw_buffers_" + placement]) == oracle.checksum(dst, 0)
+        assert int(vals["panel_images_" + placement]) == oracle.checksum(panel, 0)
+        assert float(vals[placement + "_ms"]) > 0
+    assert vals["kernel"] == "k_tile(fused)"

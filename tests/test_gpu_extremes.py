@@ -75,3 +75,18 @@ def test_flush_of_frames_at_the_coordinate_limit(gpu, oracle, rot, size):
     got = to_np(out, np.uint16).reshape(2, -1)
     for f in range(2):
         assert np.array_equal(got[f], oracle.flush_frame(frames[f], W, H, rot, rot & 1)), (size, rot, gpu.last_kernel())
+
+
+def test_a_refused_allocation_does_not_fail_the_next_launch(gpu, oracle):
+    """A runtime call that fails also stays behind as the thread's last error; the library takes it off, so that the
+    launch check of the next call does not report an allocation refused before it."""
+    import ctypes as C
+    from vvc_amd import _lib
+    p = C.c_void_p()
+    assert _lib.lib().lvgpu_malloc(C.byref(p), 1 << 50) == -2          # LVGPU_ERR_HIP: a petabyte
+    assert b"memory" in _lib.lib().lvgpu_last_error().lower()
+    frames = np.arange(3 * 64 * 64, dtype=np.uint16).reshape(3, 64, 64)
+    out = gpu.flush_rotate(to_dev(frames), 1)                            # raises if the launch check saw the old error
+    got = to_np(out, np.uint16).reshape(3, -1)
+    assert all(np.array_equal(got[f], oracle.flush_frame(frames[f], 64, 64, 1, 0)) for f in range(3))
+    assert gpu.last_kernel() == "k_tile"

@@ -41,10 +41,15 @@ int fail(int code, const char * fmt, ...)
     return code;
 }
 
+// A failed runtime call also stays behind as the thread's "last error", which the check after the next kernel launch
+// would report as that launch's: it is taken off here, so that a host can carry on after, say, a refused allocation.
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if(e_ != hipSuccess) return fail(LVGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+        if(e_ != hipSuccess) {                                                                     \
+            (void)hipGetLastError();                                                               \
+            return fail(LVGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                    \
+        }                                                                                          \
     } while(0)
 }  // namespace
 

@@ -35,7 +35,10 @@ int launch_argb_rows(int fmt, const BlendArgs & a, hipStream_t st);   // ARGB856
 #define LVGPU_LAUNCH_TRY(expr)                                                                                      \
     do {                                                                                                            \
         hipError_t e_ = (expr);                                                                                     \
-        if(e_ != hipSuccess) return host_fail(LVGPU_ERR_HIP, (std::string(#expr ": ") + hipGetErrorString(e_)).c_str()); \
+        if(e_ != hipSuccess) {                                                                                      \
+            (void)hipGetLastError(); /* not to be reported again by the check after the next launch */                  \
+            return host_fail(LVGPU_ERR_HIP, (std::string(#expr ": ") + hipGetErrorString(e_)).c_str());               \
+        }                                                                                                           \
     } while(0)
 
 template <template <int> class L, typename... Args>
