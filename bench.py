@@ -29,6 +29,10 @@ One "step" = one pass of the hot path over one batch of synthetic frames, device
                            descriptors) replayed over every frame as ONE display list with the fused flush; bytes/px
                            counts what must move (draw buffer and panel image written once each, 4 B/px) -- this
                            kernel is bound by VALU issue, not by HBM.
+Buffers are placed by region of the device memory (--placement spread, the default: draw buffers, sources + masks and
+panel images in different 96-GB regions of one arena whose region map is found by timing first, vvc_amd/placement.py;
+--placement compact leaves them where the allocator puts them; the full default run times the headline launch in
+both and reports the second as roofline.compact_placement_frac).
 Frames are sharded over ranks (one process per GPU), there is no data-path collective; torch.distributed is used only
 for the barrier, the max-over-ranks time and the gather of the per-rank times -- over gloo on host tensors by default
 (a path without a collective should not depend on RCCL coming up on the node; LVGPU_BENCH_BACKEND=nccl selects RCCL).
