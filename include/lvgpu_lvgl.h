@@ -136,7 +136,7 @@ void lvgpu_lvgl_set_color_16_swap(int swap);
 /*
  * Deferred mode (read by lvgpu_draw_ctx_init).  on = 1: on; 0: off (immediate mode: every blend call is a round trip
  * to the device, correct anywhere and two orders of magnitude slower than LVGL on a live display); -1, the default:
- * on for a display whose flush_cb is lvgpu_flush_cb -- the installation INTEGRATION.md shows, where the flush callback
+ * on for a display whose flush_cb is lvgpu_flush_cb -- the usual installation, in which the flush callback
  * draws what is queued before it looks at the buffer -- and off for a display that keeps a flush_cb of its own, which
  * has to opt in because it has to cooperate (below).  LVGL's producers issue one lv_draw_sw_blend per row of
  * a rounded, anti-aliased or text object (libraries/lvgl/src/draw/sw/lv_draw_sw_rect.c:118-330, lv_draw_sw_letter.c:
