@@ -57,20 +57,23 @@ for w in sorted(os.listdir(src)) if os.path.isdir(src) else []:
     d = os.path.join(src, w)
     line = bench_line(os.path.join(d, "kt.log"))
     stats = newest(os.path.join(d, "kt", "**", "*_kernel_stats.csv"))
-    avg_ns = calls = None
+    avg_ns = calls = kfull = None
     best_t = 0.0
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(dst, "%s_kernel_stats.csv" % w), "w") as f:
             csv.writer(f).writerows(rows)
         hdr = rows[0]
+        want_ns = line["roofline"]["launch_ms"] * 1e6 if line else None
         for r in rows[1:]:
             rec = dict(zip(hdr, r))
             if kname in rec.get("Name", ""):
-                # several instantiations may match (warm-up synth kernels do not): take the one with the most time
+                # several instantiations may match (the probe launches that find the memory regions are one): take the
+                # one whose mean duration is nearest the launch time the bench line reports, else the one with the most time
                 t = float(rec["TotalDurationNs"])
-                if avg_ns is None or t > best_t:
-                    best_t, avg_ns, calls = t, float(rec["AverageNs"]), int(rec["Calls"])
+                score = -abs(float(rec["AverageNs"]) - want_ns) if want_ns else t
+                if avg_ns is None or score > best_t:
+                    best_t, avg_ns, calls, kfull = score, float(rec["AverageNs"]), int(rec["Calls"]), rec["Name"]
     vals = {}
     for c in ("fetch", "write"):
         files = newest(os.path.join(d, c, "**", "*_counter_collection.csv"))
@@ -81,7 +84,7 @@ for w in sorted(os.listdir(src)) if os.path.isdir(src) else []:
             per_kernel[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         match = {k: v for k, v in per_kernel.items() if kname in k}
         if match:
-            k_big = max(match, key=lambda k: sum(match[k]))
+            k_big = kfull if kfull in match else max(match, key=lambda k: sum(match[k]))
             vals[c] = sum(match[k_big]) / len(match[k_big])
     if line is None:
         continue

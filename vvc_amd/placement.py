@@ -91,14 +91,16 @@ class RegionArena:
 
     # -- the region map, by timing ------------------------------------------------------------------------------------
     def _probe(self, lvgpu, anchor, slots):
-        """Time of three fused ARGB8888 blend + quarter-turn launches with draw buffers and sources in slot `anchor` and
+        """Time of three fused 32-bit-image blend + quarter-turn launches with draw buffers and sources in slot `anchor` and
         the panel images in each of `slots` (in its upper half, so that the anchor's own slot can be probed too)."""
         n, W, H = self.PROBE_FRAMES, 480, 320
         a0 = anchor * self.SLOT
         dst = self.view(a0, (n, H, W), torch.int16)
         src = self.view(a0 + 1 * GB, (n, H, W), torch.int32)
         ctx = lvgpu.DrawCtx(dst, color_16_swap=1)
-        dsc = lvgpu.BlendDsc((0, 0, W - 1, H - 1), src_buf=src, opa=255, src_format=lvgpu.SRC_ARGB8888)
+        # RGBA8888 rather than ARGB8888: the same traffic from another instantiation of the kernel, so that a kernel trace
+        # of a program that calibrates and then draws ARGB8888 images keeps the two apart
+        dsc = lvgpu.BlendDsc((0, 0, W - 1, H - 1), src_buf=src, opa=255, src_format=lvgpu.SRC_RGBA8888)
         times = {}
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for s in slots:
